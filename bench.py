@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py -- relaxation iterations/s of the MI355X-native topolow path.
+
+A "step" is one relaxation iteration (one pass over all N x N ordered pairs, plus the
+convergence check the reference runs every `convergence_check_freq`=3 iterations).
+
+  N = 1 : BASELINE.json config 3 -- synthetic N=10 000, 70 % missing, ndim=5, k0=5,
+          cooling=0.01, c_repulsion=0.01 -- one embedding on one GPU, targets resident in HBM.
+  N > 1 : BASELINE.json config 4 -- synthetic N=50 000, 90 % missing, ndim=3 -- ONE embedding
+          row-block sharded over the ranks (all-gather of position slices after every slab
+          stage over RCCL); total work fixed => "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (slab_stage_kernel):
+algorithmic bytes per launch = (4*rows*N + 8*N*ndim + 4*N) / stages, divided by its mean
+duration from HIP events recorded on the session stream around every launch in a separate
+profiled pass.  `cpu_baseline` times the CPU oracle (reference schedule, 1 core) on a bounded
+sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--n", type=int, default=0, help="override the number of points (testing)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--stages", type=int, default=0, help="fixed slab stages (0 = adaptive)")
+    return ap.parse_args()
+
+
+def workload_single(n):
+    from topolow_amd import core, synthetic
+    t0 = time.time()
+    prob = synthetic.make_problem(n, latent_dim=5, missing=0.7, seed=12345)
+    init = synthetic.initial_positions(prob.dissimilarity, 5, 12345)
+    call = core.prepare_layout_call(prob.dissimilarity, 5, 1, 5.0, 0.01, 0.01, 1e-4, 5, init, False, 3,
+                                    True)
+    return call, time.time() - t0
+
+
+def run_single(args):
+    import torch
+    from topolow_amd import _native
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    n = args.n or 10000
+    ndim = 5
+    K, W = args.steps, args.warmup
+    k0, cool, c_rep = 5.0, 0.01, 0.01
+    call, gen_s = workload_single(n)
+
+    t0 = time.time()
+    s = _native.Session(n, ndim, precision="f32")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    upload_s = time.time() - t0
+
+    def fresh(total):
+        s.set_positions(call.initial_positions)
+        # throughput run: the controller is active (checks every 3 iterations, snapshots) but
+        # the window is large enough that it never stops the run
+        s.begin(total, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 2024, args.stages)
+
+    # ---- timed pass (no profiling events) ----
+    fresh(W + K)
+    done = 0
+    while done < W:
+        done += s.enqueue(W - done)
+    s.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    while done < K:
+        got = s.enqueue(K - done)
+        if got == 0:
+            break
+        done += got
+    iters_run, stopped, last_mae = s.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert done == K and not stopped, (done, stopped)
+    res = s.finish()
+
+    # ---- profiled pass: HIP events around every stage launch on the session stream ----
+    fresh(W + K)
+    done = 0
+    while done < W:
+        done += s.enqueue(W - done)
+    s.sync()
+    s.set_profiling(True)
+    done = 0
+    while done < K:
+        done += s.enqueue(K - done)
+    stage_ms, stage_launches, check_ms, checks = s.profile()
+    s.set_profiling(False)
+    s.sync()
+
+    bytes_iter = s.bytes_per_iteration
+    stages_per_iter = stage_launches / K
+    bytes_per_launch = bytes_iter / stages_per_iter
+    avg_launch_s = stage_ms * 1e-3 / stage_launches
+    achieved = bytes_per_launch / avg_launch_s / 1e9
+
+    out = {
+        "metric": "relaxation iterations/sec (NxN pairs)",
+        "value": K / elapsed,
+        "unit": "iterations/s",
+        "n_gpus": 1,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"config 3: synthetic N={n}, 70% missing, ndim=5, k0=5, cooling=0.01, "
+                               "c_repulsion=0.01, check every 3 iterations",
+                   "n_points": n, "ndim": ndim, "schedule": "slab", "stages_per_iteration": stages_per_iter,
+                   "edges": int(call.edge_i.size)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "slab_stage_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "check_us": (check_ms * 1e3 / checks) if checks else None},
+        "final_mae": res.final_mae,
+        "final_mae_iteration": res.iterations,
+        "setup_seconds": {"generate": gen_s, "upload_encode": upload_s},
+    }
+
+    if not args.no_cpu_baseline:
+        from oracle import topolow_oracle as orc
+        ci = args.cpu_iters
+        try:
+            os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+        except Exception:
+            pass
+        t0 = time.perf_counter()
+        ref = orc.optimize_layout_exact(call.initial_positions, call.dissimilarity_matrix,
+                                        call.threshold_matrix, call.degrees, call.edge_i, call.edge_j,
+                                        call.edge_dist, call.edge_thresh, ci, k0, cool, c_rep, 1e-4, 10 ** 9,
+                                        ci, seed=2024)
+        cpu_s = time.perf_counter() - t0
+        # same number of iterations on the GPU for the MAE comparison
+        fresh(ci)
+        s.begin(ci, k0, cool, c_rep, 1e-4, 10 ** 9, ci, 2024, args.stages)
+        s.run()
+        g = s.finish()
+        out["cpu_baseline"] = {"value": ci / cpu_s, "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "sample": f"{ci} iterations of the same N={n} workload (shuffled "
+                                         "Gauss-Seidel oracle, f64, g++ -O2), incl. its final MAE check"}
+        out["mae_check"] = {"iterations": ci, "gpu_slab": g.final_mae, "cpu_oracle": ref.final_mae}
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    s.close()
+    print(json.dumps(out))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from topolow_amd import sharded
+        sharded.bench_main(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,209 @@
+/* include/topolow_relax.h -- C ABI of libtopolow_relax.so (MI355X / gfx950, HIP).
+ *
+ * Drop-in boundary for ONE path of omid-arhami/topolow v2.1.0: the native relaxation kernel
+ * `optimize_layout_exact_cpp` (reference src/optimization.cpp:109-382) that
+ * `euclidean_embedding()` reaches through
+ *     .Call(`_topolow_optimize_layout_exact_cpp`, <16 args>)        (reference R/RcppExports.R:4-6,
+ *                                                                    src/RcppExports.cpp:16-49)
+ * plus the dense post-metric `as.matrix(dist(positions))` (reference R/core.R:474).
+ *
+ * Plain pointers and sizes only; no torch / R / C++ types.  Matrices are laid out as R lays
+ * them out (column-major), so an R `.Call` shim or a ctypes/cgo/JNI stub can pass its buffers
+ * straight through.  Every function returns 0 on success or a TOPOLOW_ERR_* code and writes a
+ * message into errbuf (when given).  Inputs are never modified.
+ */
+#ifndef TOPOLOW_RELAX_H
+#define TOPOLOW_RELAX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOPOLOW_OK 0
+#define TOPOLOW_ERR_TOO_FEW_POINTS 1 /* "Need at least 2 points for embedding" (reference :131) */
+#define TOPOLOW_ERR_NONFINITE 2      /* "Numerical instability at iteration %d. ..." (:359-361) */
+#define TOPOLOW_ERR_BAD_ARGUMENT 3
+#define TOPOLOW_ERR_NO_DEVICE 4      /* no usable HIP device: there is NO CPU fallback */
+#define TOPOLOW_ERR_HIP 5            /* a HIP runtime call failed; message has the call */
+#define TOPOLOW_ERR_UNSUPPORTED 6
+
+/* Schedules (topolow_options.schedule). */
+#define TOPOLOW_SCHEDULE_AUTO 0   /* GS tournament for n <= gs_max_n, slab above */
+#define TOPOLOW_SCHEDULE_SLAB 1   /* S-stage row-owner slabs, HBM-bound, multi-workgroup */
+#define TOPOLOW_SCHEDULE_GS 2     /* exact Gauss-Seidel, round-robin tournament order, one workgroup */
+
+/* Arithmetic of positions and pair updates (topolow_options.precision). */
+#define TOPOLOW_PRECISION_AUTO 0  /* f64 for the GS kernel, f32 for the slab kernel */
+#define TOPOLOW_PRECISION_F32 1
+#define TOPOLOW_PRECISION_F64 2
+
+typedef struct topolow_options {
+  uint64_t seed;        /* seeds the pair-order / slab-order stream (the reference uses
+                           std::random_device, src/optimization.cpp:153-154) */
+  int32_t schedule;     /* TOPOLOW_SCHEDULE_* */
+  int32_t precision;    /* TOPOLOW_PRECISION_* */
+  int32_t slab_stages;  /* 0 = adaptive: max(4, pow2ceil(k/2.5)) per check interval */
+  int32_t device;       /* HIP device ordinal; -1 = current device */
+  int32_t gs_max_n;     /* AUTO switches to the slab schedule above this n; 0 = default */
+  int32_t reserved[5];
+} topolow_options;
+
+/* Run statistics, filled by topolow_optimize_layout_exact when `stats` is non-NULL. */
+typedef struct topolow_run_stats {
+  int32_t schedule_used;
+  int32_t precision_used;
+  int32_t iterations_run;   /* iterations executed before stopping (>= `iterations` out) */
+  int32_t n_checks;
+  double  device_seconds;   /* relaxation loop only, device resident */
+  double  total_seconds;    /* including upload/encode/download */
+  int64_t stage_launches;
+  int64_t reserved[4];
+} topolow_run_stats;
+
+void topolow_default_options(topolow_options* opt);
+
+/* Replaces the payload of `_topolow_optimize_layout_exact_cpp` (reference
+ * src/RcppExports.cpp:16-39 -> src/optimization.cpp:109-126), argument for argument:
+ *   initial_positions     n x ndim  float64, column-major           (NumericMatrix)
+ *   dissimilarity_matrix  n x n     float64, column-major, +Inf = unmeasured, symmetric
+ *   threshold_matrix      n x n     int32,   column-major, 0 exact / 1 ">" / -1 "<"
+ *   degrees               n         int32    (non-NA cells per row, R/core.R:341)
+ *   edge_i, edge_j        n_edges   int32, 0-based, i<j   } upper-triangle measured pairs,
+ *   edge_dist             n_edges   float64               } used by the convergence MAE only
+ *   edge_thresh           n_edges   int32                 } (src/optimization.cpp:54-81)
+ *   n_iter, k0, cooling_rate, c_repulsion, relative_epsilon, convergence_window,
+ *   convergence_check_freq, verbose  -- as in the reference.
+ * Outputs (the reference's returned list, src/optimization.cpp:375-381):
+ *   positions_out n x ndim float64 column-major; converged (0/1); iterations (= best
+ *   iteration); final_mae (= best MAE); final_k (= k at the best iteration).
+ * opt may be NULL (defaults).  stats may be NULL.
+ */
+int topolow_optimize_layout_exact(
+    const double* initial_positions, int32_t n, int32_t ndim,
+    const double* dissimilarity_matrix, const int32_t* threshold_matrix,
+    const int32_t* degrees,
+    const int32_t* edge_i, const int32_t* edge_j, const double* edge_dist,
+    const int32_t* edge_thresh, int64_t n_edges,
+    int32_t n_iter, double k0, double cooling_rate, double c_repulsion,
+    double relative_epsilon, int32_t convergence_window, int32_t convergence_check_freq,
+    int32_t verbose, const topolow_options* opt,
+    double* positions_out, int32_t* converged, int32_t* iterations, double* final_mae,
+    double* final_k, topolow_run_stats* stats, char* errbuf, size_t errlen);
+
+/* Replaces `as.matrix(stats::dist(positions))` (reference R/core.R:474):
+ * positions n x ndim float64 column-major (host) -> est_distances n x n float64 (host). */
+int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
+                          double* est_distances, int32_t device, char* errbuf, size_t errlen);
+
+/* ---------------------------------------------------------------------------------------
+ * Device-resident session: the same relaxation with inputs kept in HBM, for callers that
+ * run many iterations / many embeddings on data they already hold on the GPU (bench.py, the
+ * row-sharded multi-GPU driver).  Pointers named d_* are DEVICE pointers.
+ * ------------------------------------------------------------------------------------- */
+typedef struct topolow_session topolow_session;
+
+/* Creates a session for rows [row_begin, row_end) of an n-point problem (single GPU:
+ * row_begin = 0, row_end = n).  The session owns an encoded fp32 target block of
+ * (row_end-row_begin) x ld floats (see topolow_session_encoded_ld). */
+int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32_t row_begin,
+                           int32_t row_end, int32_t precision, int32_t device, char* errbuf,
+                           size_t errlen);
+void topolow_session_destroy(topolow_session* s);
+
+/* Encode the reference's dense inputs (host pointers, R layout) into the session's HBM
+ * block.  Only rows [row_begin,row_end) are read. */
+int topolow_session_load_dense(topolow_session* s, const double* dissimilarity_matrix,
+                               const int32_t* threshold_matrix, const int32_t* degrees,
+                               char* errbuf, size_t errlen);
+/* COO entry for problems too large for dense host matrices (BASELINE config 4): edges are
+ * the upper-triangle measured pairs (host pointers); degrees as above. */
+int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const int32_t* edge_j,
+                             const double* edge_dist, const int32_t* edge_thresh,
+                             int64_t n_edges, const int32_t* degrees, char* errbuf,
+                             size_t errlen);
+/* Edge list used by the convergence MAE (host pointers).  For a row-sharded session pass
+ * only the edges this rank should reduce (e.g. those with edge_i in its row block). */
+int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const int32_t* edge_j,
+                              const double* edge_dist, const int32_t* edge_thresh,
+                              int64_t n_edges, char* errbuf, size_t errlen);
+/* Positions: n x ndim float64 column-major host buffer. */
+int topolow_session_set_positions(topolow_session* s, const double* positions, char* errbuf,
+                                  size_t errlen);
+int topolow_session_get_positions(topolow_session* s, double* positions, char* errbuf,
+                                  size_t errlen);
+
+/* Starts a run: resets the controller (best = DBL_MAX, k = k0, iteration 0). */
+int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double cooling_rate,
+                          double c_repulsion, double relative_epsilon,
+                          int32_t convergence_window, int32_t convergence_check_freq,
+                          uint64_t seed, int32_t slab_stages, char* errbuf, size_t errlen);
+/* Enqueues up to max_iters iterations (whole check intervals) on the session stream and
+ * returns without waiting; *enqueued = iterations enqueued (0 when the run is over). */
+int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqueued,
+                            char* errbuf, size_t errlen);
+/* Waits for everything enqueued; reports progress. */
+int topolow_session_sync(topolow_session* s, int32_t* iterations_run, int32_t* stopped,
+                         double* last_mae, char* errbuf, size_t errlen);
+/* Restores the best snapshot and returns the reference's result fields. */
+int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* converged,
+                           int32_t* iterations, double* final_mae, double* final_k,
+                           char* errbuf, size_t errlen);
+/* Per-kernel timing for roofline accounting: while enabled, every slab-stage launch and
+ * every convergence check is bracketed by HIP events on the session stream.
+ * topolow_session_profile waits for the stream, returns the summed durations (ms) and launch
+ * counts since profiling was enabled, and resets them. */
+int topolow_session_set_profiling(topolow_session* s, int32_t enable);
+int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage_launches,
+                            double* check_ms, int64_t* checks, char* errbuf, size_t errlen);
+/* HIP stream (hipStream_t) the session launches on, for event timing by the caller. */
+void* topolow_session_stream(topolow_session* s);
+/* Number of slab-stage kernel launches so far, and the algorithmic bytes one iteration
+ * moves (4*rows*n + 8*n*ndim + 4*n). */
+int64_t topolow_session_stage_launches(const topolow_session* s);
+int64_t topolow_session_bytes_per_iteration(const topolow_session* s);
+
+/* ---------------------------------------------------------------------------------------
+ * Row-sharded building blocks (one process per GPU; the all-gather between stages is the
+ * caller's, e.g. torch.distributed/RCCL).  d_pos_* are device pointers to n x ndim
+ * row-major positions in the session's precision.
+ * ------------------------------------------------------------------------------------- */
+/* Launches stage `stage` of iteration `iter` (0-based) for the session's row block: reads
+ * all n positions from d_pos_in, writes rows [row_begin,row_end) of d_pos_out. */
+int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_out,
+                          int32_t iter, int32_t stage, int32_t n_stages, double k,
+                          char* errbuf, size_t errlen);
+/* Partial edge error of this session's edge list on d_pos: (sum, count). Synchronous. */
+int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* sum,
+                               int64_t* count, char* errbuf, size_t errlen);
+
+/* ---------------------------------------------------------------------------------------
+ * Host-side helpers exported for tests and integrators (no GPU needed).
+ * ------------------------------------------------------------------------------------- */
+/* Slab plan of iteration `iter`: writes n_stages x 4 int32 (r0_begin, r0_end, r1_begin,
+ * r1_end; second range empty unless the slab wraps) in execution order; returns n_stages. */
+int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t iter,
+                          int32_t* ranges_out, int32_t max_stages);
+/* Stage count the adaptive policy picks for spring constant k. */
+int32_t topolow_slab_stages_for_k(double k);
+/* Visiting order of the GS tournament schedule for iteration `iter`: n(n-1)/2 pairs
+ * (a,b) as 2 int32 each, in an order equivalent to what the kernel executes. */
+int64_t topolow_gs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_t* pairs_out);
+/* fp32 target encoding used in HBM: value with the 2 low mantissa bits replaced by the
+ * threshold code (0 exact, 1 ">", 2 "<", 3 skip); +Inf = unmeasured. */
+uint32_t topolow_encode_target(double dissimilarity, int32_t threshold_code);
+double topolow_decode_target(uint32_t bits, int32_t* threshold_code);
+/* Convergence controller (reference src/optimization.cpp:303-357) on a scripted MAE
+ * sequence; same code the device runs. */
+int topolow_controller_script(const double* mae_seq, const int32_t* iter_seq,
+                              const double* k_seq, int32_t n_obs, double k0, int32_t window,
+                              double eps, int32_t* stopped_at_obs, int32_t* snapshot_flags,
+                              double* best_mae, double* best_k, int32_t* best_iter);
+const char* topolow_relax_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPOLOW_RELAX_H */

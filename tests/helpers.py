@@ -1,0 +1,43 @@
+"""Shared test helpers: run the host driver with the CPU oracle standing in for the `.Call`
+(tests only -- the product has no such path)."""
+import numpy as np
+
+import oracle
+from oracle import topolow_oracle as orc
+from topolow_amd import core
+
+
+def oracle_native(seed=0, order_mode=orc.ORDER_SEEDED):
+    def fn(call):
+        return orc.optimize_layout_exact(
+            call.initial_positions, call.dissimilarity_matrix, call.threshold_matrix, call.degrees,
+            call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.n_iter, call.k0,
+            call.cooling_rate, call.c_repulsion, call.relative_epsilon, call.convergence_window,
+            call.convergence_check_freq, call.verbose, seed=seed, order_mode=order_mode)
+    return fn
+
+
+def numpy_pdist(p):
+    p = np.asarray(p, float)
+    d = p[:, None, :] - p[None, :, :]
+    return np.sqrt((d * d).sum(-1))
+
+
+def embed_with_oracle(D, ndim, mapping_max_iter=1000, k0=core._MISSING, cooling_rate=core._MISSING,
+                      c_repulsion=core._MISSING, relative_epsilon=1e-4, convergence_counter=5,
+                      initial_positions=None, write_positions_to_csv=False, output_dir=core._MISSING,
+                      verbose=False, convergence_check_freq=3, preserve_order=False, seed=0,
+                      rng=None):
+    return core._embed_with(oracle_native(seed), numpy_pdist, D, ndim, mapping_max_iter, k0,
+                            cooling_rate, c_repulsion, relative_epsilon, convergence_counter,
+                            initial_positions, write_positions_to_csv, output_dir, verbose,
+                            convergence_check_freq, preserve_order,
+                            rng if rng is not None else np.random.default_rng(seed))
+
+
+def quickstart_matrix():
+    """Reference README.md:54-69: S1,S2,S3,V1,V2 with V1-V2 missing."""
+    pts = np.array([[0, 0], [3, 0], [4, 4], [2, 2], [0, 4]], dtype=float)
+    D = numpy_pdist(pts)
+    D[3, 4] = D[4, 3] = np.nan
+    return core.RMatrix(D, ["S1", "S2", "S3", "V1", "V2"])

@@ -1,0 +1,114 @@
+"""C-ABI library: loads without a GPU, exports every symbol include/topolow_relax.h declares,
+host-side helpers agree with the oracle / with first principles, and compute entry points
+refuse to run without a device (no CPU fallback)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import topolow_oracle as orc
+from topolow_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "relax_golden.json")))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load()
+    header = open(os.path.join(ROOT, "include", "topolow_relax.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(topolow_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 25
+    for nm in sorted(names):
+        assert hasattr(lib, nm), f"{nm} declared in include/topolow_relax.h but not exported"
+
+
+def test_target_encoding_roundtrip():
+    rng = np.random.default_rng(0)
+    for t in list(rng.uniform(0, 50, 200)) + [0.0, 1e-30, 3.4e38, 1e300, -2.5]:
+        for code in (0, 1, -1):
+            w = _native.encode_target(t, code)
+            v, c = _native.decode_target(w)
+            assert c == code
+            if abs(t) < 3e38:
+                assert v == pytest.approx(t, rel=3e-7, abs=1e-37)
+            else:
+                assert np.isfinite(v)   # huge finite targets stay measured
+    for bad in (np.inf, -np.inf, np.nan):
+        v, c = _native.decode_target(_native.encode_target(bad, 1))
+        assert v == np.inf and c == 0   # not finite -> unmeasured (reference :221)
+
+
+@pytest.mark.parametrize("n,stages", [(10000, 4), (10001, 16), (257, 8), (50000, 64), (33, 4), (7, 16)])
+def test_slab_plan_covers_every_column_once(n, stages):
+    n4 = (n + 3) // 4 * 4
+    for it in range(5):
+        plan = _native.slab_plan(n, stages, 1234, it)
+        assert 1 <= len(plan) <= stages
+        cover = np.zeros(n4, dtype=int)
+        for b0, e0, b1, e1 in plan:
+            assert b0 % 4 == 0 and e0 % 4 == 0 and b1 % 4 == 0 and e1 % 4 == 0
+            cover[b0:e0] += 1
+            cover[b1:e1] += 1
+        assert np.all(cover == 1)
+    assert not np.array_equal(_native.slab_plan(n, stages, 1234, 0), _native.slab_plan(n, stages, 1234, 1)) \
+        or n < 64
+
+
+def test_slab_stage_policy():
+    assert _native.slab_stages_for_k(0.1) == 4 and _native.slab_stages_for_k(10.0) == 4
+    assert _native.slab_stages_for_k(14.76) == 8 and _native.slab_stages_for_k(30.0) == 16
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 33, 64, 101])
+def test_gs_pair_order_is_a_permutation_of_all_pairs_in_disjoint_rounds(n):
+    for it in range(3):
+        pairs = _native.gs_pair_order(n, 99, it)
+        key = {(min(a, b), max(a, b)) for a, b in pairs}
+        assert len(key) == n * (n - 1) // 2 and all(a != b for a, b in pairs)
+        per_round = n // 2
+        for r in range(0, len(pairs), per_round):
+            pts = pairs[r:r + per_round].ravel()
+            assert len(set(pts.tolist())) == len(pts)   # a round's pairs are disjoint
+    if n > 3:
+        assert not np.array_equal(_native.gs_pair_order(n, 99, 0), _native.gs_pair_order(n, 99, 1))
+
+
+@pytest.mark.parametrize("case", GOLD["G4_controller"], ids=lambda c: f"{c['name']}-w{c['window']}")
+def test_device_controller_code_matches_golden_and_oracle(case):
+    maes = [float(m) if m not in ("nan",) else float("nan") for m in case["maes"]]
+    mine = _native.controller_script(maes, case["iters"], case["ks"], case["k0"], case["window"], case["eps"])
+    ref = orc.controller_script(maes, case["iters"], case["ks"], case["k0"], case["window"], case["eps"])
+    for key in ("stopped_at", "best_iter", "best_mae", "best_k"):
+        assert mine[key] == ref[key] == case["expect"][key]
+    assert list(mine["snapshots"]) == list(ref["snapshots"])
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device error path")
+def test_no_cpu_fallback_without_device():
+    D = np.array([[np.inf, 1.0], [1.0, np.inf]])
+    T = np.zeros((2, 2), np.int32)
+    with pytest.raises(_native.NativeError) as ei:
+        _native.optimize_layout_exact_arrays(np.zeros((2, 2)), D, T, [1, 1], [0], [1], [1.0], [0], 5, 1.0,
+                                             0.1, 0.1, 1e-4, 5, 3, seed=1)
+    assert ei.value.code == _native.ERR_NO_DEVICE
+    with pytest.raises(_native.NativeError) as ei:
+        _native.est_distances(np.zeros((3, 2)))
+    assert ei.value.code == _native.ERR_NO_DEVICE
+
+
+def test_too_few_points_message():
+    with pytest.raises(_native.NativeError, match="Need at least 2 points for embedding"):
+        _native.optimize_layout_exact_arrays(np.zeros((1, 2)), np.zeros((1, 1)), np.zeros((1, 1), np.int32),
+                                             [0], [], [], [], [], 5, 1.0, 0.1, 0.1, 1e-4, 5, 3, seed=1)

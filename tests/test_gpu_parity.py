@@ -1,0 +1,340 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every test calls the HIP path through
+the C ABI (libtopolow_relax.so via topolow_amd._native) and checks it against the CPU oracle
+(reference semantics) or, for the slab schedule, stage-for-stage against the CPU slab model
+and statistically against the oracle.
+
+Tolerances (stated per test):
+  * GS schedule, f64: the kernel performs the oracle's operations in an equivalent order ->
+    positions equal to 1e-12 absolute (bit-for-bit in practice), identical controller fields.
+  * slab stage, f64: vs the model <= 1e-11 relative (only summation order differs).
+  * slab stage, f32: <= 2e-4 relative to the largest displacement (fp32 + v_rcp/v_sqrt).
+  * slab end-to-end vs the reference schedule (oracle GS): statistical -- final MAE within
+    max(3 sd, 5 %) of the oracle's seed distribution; est_distances mean relative difference
+    no larger than 1.5x the oracle's own seed-to-seed spread (the reference's own run-to-run
+    tolerance is relative 1e-2, tests/testthat/test-deprecated.R:65-67).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import topolow_oracle as orc
+from tests.conftest import layout_call_args
+from tests.helpers import numpy_pdist, quickstart_matrix
+from tests.models import slab_model
+from topolow_amd import _native, core, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_problem(n, dim, missing, seed, thresholds=0.0, n_iter=20, k0=3.0, cool=0.05, c_rep=0.02,
+                    check_freq=3, window=5, eps=1e-4):
+    prob = synthetic.make_problem(n, latent_dim=dim, missing=missing, seed=seed)
+    D = prob.dissimilarity
+    if thresholds > 0:
+        rng = np.random.default_rng(seed + 1)
+        M = D.astype(object)
+        iu, ju = np.triu_indices(n, 1)
+        for a, b in zip(iu, ju):
+            if not np.isnan(D[a, b]):
+                u = rng.random()
+                if u < thresholds / 2:
+                    M[a, b] = M[b, a] = ">" + repr(float(D[a, b]) * 0.9)
+                elif u < thresholds:
+                    M[a, b] = M[b, a] = "<" + repr(float(D[a, b]) * 1.1)
+            else:
+                M[a, b] = M[b, a] = None
+        for a in range(n):
+            M[a, a] = "0"
+        D = M
+    init = synthetic.initial_positions(prob.dissimilarity, dim, seed)
+    return core.prepare_layout_call(D, dim, n_iter, k0, cool, c_rep, eps, window, init, False, check_freq,
+                                    True), prob
+
+
+def _oracle_with_gs_order(call, seed, arith="f64"):
+    n = call.initial_positions.shape[0]
+
+    def order_fn(it, arr):
+        arr[:] = _native.gs_pair_order(n, seed, it)
+
+    return orc.optimize_layout_exact(*layout_call_args(call), order_mode=orc.ORDER_SUPPLIED,
+                                     order_fn=order_fn, arith=arith)
+
+
+# ----------------------------------------------------------------------------------------
+# GS schedule: exact parity with the oracle replaying the same pair order
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,missing,thr", [(2, 2, 0.0, 0.0), (3, 1, 0.0, 0.0), (5, 2, 0.2, 0.0),
+                                               (8, 3, 0.3, 0.3), (33, 5, 0.5, 0.2), (64, 4, 0.7, 0.1),
+                                               (101, 5, 0.7, 0.0), (257, 3, 0.9, 0.15), (300, 10, 0.6, 0.0)])
+def test_gs_f64_matches_oracle_same_order(n, dim, missing, thr):
+    call, _ = _random_problem(n, dim, missing if n > 4 else 0.0, seed=n, thresholds=thr, n_iter=25)
+    seed = 1000 + n
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="gs",
+                                               precision="f64")
+    ref = _oracle_with_gs_order(call, seed)
+    assert got.info["schedule"] == "gs" and got.info["precision"] == "f64"
+    assert np.abs(got.positions - ref.positions).max() <= 1e-12
+    assert got.converged == ref.converged and got.iterations == ref.iterations
+    assert got.final_mae == pytest.approx(ref.final_mae, rel=1e-12)
+    assert got.final_k == ref.final_k
+    assert got.info["iterations_run"] == ref.iters_run
+
+
+def test_gs_f32_close_to_oracle_f32_same_order():
+    """fp32 positions: compared with the oracle's own float32 arithmetic, same order."""
+    call, _ = _random_problem(120, 5, 0.6, seed=7, n_iter=15)
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=5, schedule="gs", precision="f32")
+    ref = _oracle_with_gs_order(call, 5, arith="f32")
+    scale = np.abs(ref.positions).max()
+    assert np.abs(got.positions - ref.positions).max() <= 1e-4 * scale
+    assert got.final_mae == pytest.approx(ref.final_mae, rel=1e-4)
+
+
+def test_gs_convergence_controller_end_to_end_quickstart():
+    """README.md:54-87 of the reference on the GPU: converges, restores the best snapshot,
+    V1-V2 ~ 2.83; and equals the oracle replay exactly."""
+    m = quickstart_matrix()
+    call = core.prepare_layout_call(m, 2, 1000, 5.0, 0.03, 0.7, 1e-4, 5, None, False, 3, False,
+                                    np.random.default_rng(2))
+    vals = []
+    for seed in range(6):
+        got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="gs")
+        ref = _oracle_with_gs_order(call, seed)
+        assert got.converged and got.iterations == ref.iterations < 1000
+        assert np.abs(got.positions - ref.positions).max() <= 1e-12
+        est = _native.est_distances(got.positions)
+        vals.append(est[call.names.index("V1"), call.names.index("V2")])
+    assert 2.6 < np.mean(vals) < 3.1
+
+
+def test_gs_distribution_matches_shuffled_reference_order():
+    """The tournament order is a legitimate random order: final MAE over seeds is distributed
+    like the oracle's std::shuffle order (reference :196)."""
+    call, _ = _random_problem(150, 3, 0.6, seed=21, n_iter=300, k0=8.0, cool=0.03, c_rep=0.01)
+    ref = [orc.optimize_layout_exact(*layout_call_args(call), seed=s).final_mae for s in range(12)]
+    got = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=s, schedule="gs").final_mae
+           for s in range(12)]
+    assert abs(np.mean(got) - np.mean(ref)) <= max(3 * np.std(ref) / np.sqrt(12) * 2, 0.03 * np.mean(ref))
+
+
+def test_gs_nonfinite_and_small_n_errors():
+    call, _ = _random_problem(20, 2, 0.3, seed=3, n_iter=40)
+    bad = call.initial_positions.copy()
+    bad[4, 0] = np.nan
+    args = list(layout_call_args(call)); args[0] = bad
+    with pytest.raises(_native.NativeError, match=r"Numerical instability at iteration 10\. Reduce k0 or c_repulsion\."):
+        _native.optimize_layout_exact_arrays(*args, seed=1, schedule="gs")
+    with pytest.raises(orc.OracleError, match=r"Numerical instability at iteration 10\."):
+        orc.optimize_layout_exact(*args, seed=1)
+
+
+# ----------------------------------------------------------------------------------------
+# slab schedule: stage-for-stage against the CPU model
+# ----------------------------------------------------------------------------------------
+def _model_run(call, seed, stages_fixed, n_iter, arith):
+    n = call.initial_positions.shape[0]
+    plans, counts = [], []
+    k = call.k0
+    for it in range(n_iter):
+        st = stages_fixed if stages_fixed else _native.slab_stages_for_k(k)
+        p = _native.slab_plan(n, st, seed, it)
+        plans.append(p); counts.append(len(p))
+        k *= 1.0 - call.cooling_rate
+    mx = max(counts)
+    plan = np.zeros((n_iter, mx, 4), np.int32)
+    for it, p in enumerate(plans):
+        plan[it, : len(p)] = p
+    return slab_model.run(call.initial_positions, call.dissimilarity_matrix, call.threshold_matrix,
+                          call.degrees, plan, np.array(counts, np.int32), call.k0, call.cooling_rate,
+                          call.c_repulsion, arith)
+
+
+def _decode_rounded(call):
+    """The slab path keeps targets as 4-ulp-rounded fp32; give the model the same values."""
+    D = call.dissimilarity_matrix.copy()
+    fin = np.isfinite(D)
+    u = D[fin].astype(np.float32).view(np.uint32)
+    mag = ((u & np.uint32(0x7FFFFFFF)) + np.uint32(2)) & np.uint32(0xFFFFFFFC)
+    out = ((u & np.uint32(0x80000000)) | mag).view(np.float32).astype(np.float64)
+    sample = D[fin][:64]
+    assert all(_native.decode_target(_native.encode_target(v, 0))[0] == o for v, o in zip(sample, out[:64]))
+    D[fin] = out
+    return D
+
+
+@pytest.mark.parametrize("n,dim,missing,thr,stages", [(256, 5, 0.7, 0.0, 4), (301, 3, 0.5, 0.2, 4),
+                                                      (1030, 5, 0.7, 0.1, 8), (2050, 2, 0.9, 0.0, 16),
+                                                      (777, 10, 0.6, 0.0, 4), (513, 1, 0.3, 0.0, 4)])
+def test_slab_f64_matches_model(n, dim, missing, thr, stages):
+    call, _ = _random_problem(n, dim, missing, seed=n + 1, thresholds=thr, n_iter=6, check_freq=3)
+    import dataclasses
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    seed = 42
+    s = _native.Session(n, dim, precision="f64")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    s.set_positions(call.initial_positions)
+    s.begin(6, call.k0, call.cooling_rate, call.c_repulsion, 1e-12, 1000, 3, seed, stages)
+    s.run()
+    got = s.get_positions()
+    want, _k = _model_run(call_r, seed, stages, 6, "f64")
+    scale = np.abs(want - call.initial_positions).max()
+    assert np.abs(got - want).max() <= 1e-11 * max(scale, 1.0)
+    res = s.finish()
+    sm, cnt = orc.edge_error(got, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    if res.iterations == 6:
+        assert res.final_mae == pytest.approx(sm / cnt, rel=1e-12)
+    s.close()
+
+
+@pytest.mark.parametrize("n,dim,stages", [(1024, 5, 4), (1500, 3, 0), (999, 2, 8)])
+def test_slab_f32_close_to_model(n, dim, stages):
+    call, _ = _random_problem(n, dim, 0.7, seed=n + 5, thresholds=0.1, n_iter=9, k0=12.0 if stages == 0 else 4.0)
+    import dataclasses
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    seed = 9
+    s = _native.Session(n, dim, precision="f32")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    s.set_positions(call.initial_positions)
+    s.begin(9, call.k0, call.cooling_rate, call.c_repulsion, 1e-12, 1000, 3, seed, stages)
+    s.run()
+    got = s.get_positions()
+    want, _k = _model_run(call_r, seed, stages, 9, "f64")
+    scale = np.abs(want - call.initial_positions).max()
+    assert np.abs(got - want).max() <= 2e-4 * scale
+    s.close()
+
+
+def test_coo_load_equals_dense_load():
+    call, _ = _random_problem(700, 3, 0.8, seed=31, thresholds=0.2, n_iter=4)
+    outs = []
+    for mode in ("dense", "coo"):
+        s = _native.Session(700, 3, precision="f64")
+        if mode == "dense":
+            s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+        else:
+            s.load_coo(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.degrees)
+        s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        s.set_positions(call.initial_positions)
+        s.begin(4, 3.0, 0.05, 0.02, 1e-4, 5, 2, 77, 4)
+        s.run()
+        outs.append(s.get_positions())
+        s.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+# ----------------------------------------------------------------------------------------
+# slab schedule end-to-end vs the reference schedule (statistical), plus post metrics
+# ----------------------------------------------------------------------------------------
+def test_slab_statistical_parity_with_oracle():
+    n, dim = 1500, 5
+    call, prob = _random_problem(n, dim, 0.7, seed=777, n_iter=1000, k0=14.76, cool=0.0364, c_rep=0.00294)
+    truth = prob.dissimilarity
+    ref = [orc.optimize_layout_exact(*layout_call_args(call), seed=s) for s in range(4)]
+    ref_mae = np.array([r.final_mae for r in ref])
+    ref_it = np.array([r.iterations for r in ref])
+    ref_est = [numpy_pdist(r.positions) for r in ref]
+    iu = np.triu_indices(n, 1)
+    rel = lambda a, b: float(np.mean(np.abs(a[iu] - b[iu])) / np.mean(b[iu]))
+    ref_spread = max(rel(ref_est[q], ref_est[0]) for q in range(1, 4))
+    for seed in range(3):
+        got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="slab")
+        assert got.info["schedule"] == "slab" and got.info["precision"] == "f32"
+        assert got.converged
+        assert abs(got.final_mae - ref_mae.mean()) <= max(3 * ref_mae.std(), 0.05 * ref_mae.mean())
+        assert 0.6 * ref_it.min() <= got.iterations <= 1.6 * ref_it.max()
+        est = _native.est_distances(got.positions)
+        assert rel(est, ref_est[0]) <= 1.5 * ref_spread + 0.005
+        _, mae_post = oracle.post_metrics(got.positions, truth)
+        _, mae_ref = oracle.post_metrics(ref[0].positions, truth)
+        assert mae_post == pytest.approx(mae_ref, rel=0.08)
+        # the MAE the device controller reported is the oracle's MAE of the returned positions
+        sm, cnt = orc.edge_error(got.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        assert got.final_mae == pytest.approx(sm / cnt, rel=2e-5)
+
+
+def test_est_distances_matches_numpy():
+    rng = np.random.default_rng(0)
+    for n, d in ((5, 2), (300, 5), (1111, 3)):
+        p = rng.normal(size=(n, d))
+        est = _native.est_distances(p)
+        assert np.allclose(est, numpy_pdist(p), rtol=1e-14, atol=1e-14)
+        assert np.array_equal(est, est.T) and np.all(np.diag(est) == 0)
+
+
+def test_euclidean_embedding_drop_in_on_gpu(tmp_path):
+    """The public entry point end to end on the device, with the reference's own test cases
+    (tests/testthat/test-core.R:90-139, test-edge-cases.R:66-82, test-deprecated.R:4-25)."""
+    import topolow_amd
+    topolow_amd.set_seed(123)
+    m = np.array([["0", ">2", "3"], [">2", "0", "4"], ["3", "4", "0"]], dtype=object)
+    m[0, 2] = m[2, 0] = None
+    r = topolow_amd.euclidean_embedding(m, 2, 10, 1.0, 0.01, 0.01)
+    assert np.isfinite(r.est_distances).all() and r.est_distances[0, 2] == r.est_distances[2, 0]
+    tri = core.RMatrix(np.array([[0, 1, 2], [1, 0, 1], [2, 1, 0]], float), ["A", "B", "C"])
+    r = topolow_amd.euclidean_embedding(tri, ndim=2, mapping_max_iter=10, k0=1.0, cooling_rate=0.01,
+                                        c_repulsion=0.01)
+    ix = {nm: q for q, nm in enumerate(r.names)}
+    d = lambda p, q: r.est_distances[ix[p], ix[q]]
+    assert d("A", "C") > d("A", "B") and d("A", "C") < d("A", "B") + d("B", "C")
+    assert r.r_class == "topolow" and "MAE:" in str(r)
+    sp = np.full((4, 4), np.nan); sp[0, 1] = sp[1, 0] = 5; np.fill_diagonal(sp, 0)
+    r = topolow_amd.euclidean_embedding(sp, 2, 50, 1.0, 0.01, 0.1)
+    assert np.isfinite(r.positions).all()
+    with pytest.warns(DeprecationWarning, match="was deprecated"):
+        r = topolow_amd.create_topolow_map(np.array([[0, 2, 3], [2, 0, 4], [3, 4, 0]], float), ndim=2,
+                                           mapping_max_iter=10, k0=1.0, cooling_rate=0.001, c_repulsion=0.01)
+    assert "est_distances" in r
+    r = topolow_amd.euclidean_embedding(quickstart_matrix(), 2, 1000, 5, 0.03, 0.7,
+                                        write_positions_to_csv=True, output_dir=str(tmp_path / "o"))
+    assert (tmp_path / "o" / "Positions_dim_2_k0_5.0000_cooling_0.0300_c_repulsion_0.7000.csv").exists()
+    assert 2.5 < r.est_distances[r.names.index("V1"), r.names.index("V2")] < 3.2
+
+
+# ----------------------------------------------------------------------------------------
+# full BASELINE size (N = 10 000, ndim 5, 70 % missing): size-independent properties
+# ----------------------------------------------------------------------------------------
+def test_full_size_properties():
+    n, dim = 10000, 5
+    prob = synthetic.make_problem(n, latent_dim=dim, missing=0.7, seed=12345)
+    init = synthetic.initial_positions(prob.dissimilarity, dim, 12345)
+    call = core.prepare_layout_call(prob.dissimilarity, dim, 12, 5.0, 0.01, 0.01, 1e-4, 5, init, False, 3,
+                                    True)
+    s = _native.Session(n, dim, precision="f32")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+
+    def run(init_pos, seed):
+        s.set_positions(init_pos)
+        s.begin(12, 5.0, 0.01, 0.01, 1e-4, 5, 3, seed, 0)
+        s.run()
+        return s.finish()
+
+    a = run(call.initial_positions, 5)
+    b = run(call.initial_positions, 5)
+    assert np.array_equal(a.positions, b.positions)            # deterministic for a fixed seed
+    # (1) reported MAE == oracle's edge MAE of the returned positions
+    sm, cnt = orc.edge_error(a.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert a.final_mae == pytest.approx(sm / cnt, rel=2e-5) and a.iterations == 12
+    # (2) translation equivariance: shifting every start point shifts every result point
+    shift = np.array([3.0, -2.0, 1.0, 0.5, -4.0])
+    c = run(call.initial_positions + shift, 5)
+    assert np.abs((c.positions - shift) - a.positions).max() <= 5e-3
+    # (3) the error falls monotonically over these first checks and positions stay finite
+    assert np.isfinite(a.positions).all() and a.final_mae < 0.9 * (
+        orc.edge_error(call.initial_positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)[0] / cnt)
+    # (4) one stage of the slab model on a row sample agrees with the device (spot check)
+    s.set_positions(call.initial_positions)
+    s.begin(1, 5.0, 0.01, 0.01, 1e-4, 5, 1, 11, 4)
+    s.run()
+    got = s.get_positions()
+    plan = _native.slab_plan(n, 4, 11, 0)
+    pos = call.initial_positions
+    for rg in plan:
+        pos = slab_model.stage(pos, call.dissimilarity_matrix, call.threshold_matrix, call.degrees,
+                               [r for r in rg.reshape(2, 2) if r[1] > r[0]], 5.0, 0.01, "f64")
+    scale = np.abs(pos - call.initial_positions).max()
+    assert np.abs(got - pos).max() <= 3e-4 * scale
+    s.close()

@@ -1,0 +1,441 @@
+"""ctypes binding of libtopolow_relax.so (include/topolow_relax.h) -- the MI355X native path.
+
+This is the Python twin of the R `.Call` shim: it hands the `.Call` payload of
+`optimize_layout_exact_cpp` (reference R/RcppExports.R:4-6) to the HIP library.  There is
+NO fallback: if the library is missing or no HIP device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtopolow_relax.so")
+
+SCHEDULE_AUTO, SCHEDULE_SLAB, SCHEDULE_GS = 0, 1, 2
+PRECISION_AUTO, PRECISION_F32, PRECISION_F64 = 0, 1, 2
+
+OK = 0
+ERR_TOO_FEW_POINTS, ERR_NONFINITE, ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = \
+    1, 2, 3, 4, 5, 6
+
+
+class NativeError(RuntimeError):
+    """An error raised by libtopolow_relax (the R shim turns these into R errors)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class TopolowOptions(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("schedule", C.c_int32), ("precision", C.c_int32),
+                ("slab_stages", C.c_int32), ("device", C.c_int32), ("gs_max_n", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class TopolowRunStats(C.Structure):
+    _fields_ = [("schedule_used", C.c_int32), ("precision_used", C.c_int32),
+                ("iterations_run", C.c_int32), ("n_checks", C.c_int32),
+                ("device_seconds", C.c_double), ("total_seconds", C.c_double),
+                ("stage_launches", C.c_int64), ("reserved", C.c_int64 * 4)]
+
+
+# Additive backend options (the reference's function signatures stay untouched; this mirrors
+# what an R user would set through options(topolow.*)).
+options: Dict[str, Any] = dict(seed=None, schedule="auto", precision="auto", slab_stages=0,
+                               device=-1, gs_max_n=0)
+_host_rng = np.random.default_rng()
+
+_SCHEDULES = {"auto": SCHEDULE_AUTO, "slab": SCHEDULE_SLAB, "gs": SCHEDULE_GS}
+_PRECISIONS = {"auto": PRECISION_AUTO, "f32": PRECISION_F32, "f64": PRECISION_F64}
+
+
+def set_seed(seed: Optional[int]) -> None:
+    """Seed both the random-walk initial positions and the native pair/slab order stream
+    (the reference seeds only the former from R's RNG; its shuffle uses random_device)."""
+    global _host_rng
+    options["seed"] = seed
+    _host_rng = np.random.default_rng(seed)
+
+
+def host_rng() -> np.random.Generator:
+    return _host_rng
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C topolow_amd/csrc`. topolow_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.topolow_relax_version.restype = C.c_char_p
+    lib.topolow_default_options.argtypes = [C.POINTER(TopolowOptions)]
+    lib.topolow_optimize_layout_exact.restype = C.c_int
+    lib.topolow_optimize_layout_exact.argtypes = [
+        dp, C.c_int32, C.c_int32, dp, ip, ip, ip, ip, dp, ip, C.c_int64,
+        C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
+        C.c_int32, C.POINTER(TopolowOptions), dp, ip, ip, dp, dp, C.POINTER(TopolowRunStats),
+        C.c_char_p, C.c_size_t]
+    lib.topolow_est_distances.restype = C.c_int
+    lib.topolow_est_distances.argtypes = [dp, C.c_int32, C.c_int32, dp, C.c_int32, C.c_char_p,
+                                          C.c_size_t]
+    vp = C.c_void_p
+    lib.topolow_session_create.restype = C.c_int
+    lib.topolow_session_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
+    lib.topolow_session_destroy.argtypes = [vp]
+    lib.topolow_session_destroy.restype = None
+    lib.topolow_session_load_dense.restype = C.c_int
+    lib.topolow_session_load_dense.argtypes = [vp, dp, ip, ip, C.c_char_p, C.c_size_t]
+    lib.topolow_session_load_coo.restype = C.c_int
+    lib.topolow_session_load_coo.argtypes = [vp, ip, ip, dp, ip, C.c_int64, ip, C.c_char_p,
+                                             C.c_size_t]
+    lib.topolow_session_set_edges.restype = C.c_int
+    lib.topolow_session_set_edges.argtypes = [vp, ip, ip, dp, ip, C.c_int64, C.c_char_p, C.c_size_t]
+    lib.topolow_session_set_positions.restype = C.c_int
+    lib.topolow_session_set_positions.argtypes = [vp, dp, C.c_char_p, C.c_size_t]
+    lib.topolow_session_get_positions.restype = C.c_int
+    lib.topolow_session_get_positions.argtypes = [vp, dp, C.c_char_p, C.c_size_t]
+    lib.topolow_session_begin.restype = C.c_int
+    lib.topolow_session_begin.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
+                                          C.c_char_p, C.c_size_t]
+    lib.topolow_session_enqueue.restype = C.c_int
+    lib.topolow_session_enqueue.argtypes = [vp, C.c_int32, ip, C.c_char_p, C.c_size_t]
+    lib.topolow_session_sync.restype = C.c_int
+    lib.topolow_session_sync.argtypes = [vp, ip, ip, dp, C.c_char_p, C.c_size_t]
+    lib.topolow_session_finish.restype = C.c_int
+    lib.topolow_session_finish.argtypes = [vp, dp, ip, ip, dp, dp, C.c_char_p, C.c_size_t]
+    lib.topolow_session_set_profiling.restype = C.c_int
+    lib.topolow_session_set_profiling.argtypes = [vp, C.c_int32]
+    lib.topolow_session_profile.restype = C.c_int
+    lib.topolow_session_profile.argtypes = [vp, dp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64),
+                                            C.c_char_p, C.c_size_t]
+    lib.topolow_session_stream.restype = vp
+    lib.topolow_session_stream.argtypes = [vp]
+    lib.topolow_session_stage_launches.restype = C.c_int64
+    lib.topolow_session_stage_launches.argtypes = [vp]
+    lib.topolow_session_bytes_per_iteration.restype = C.c_int64
+    lib.topolow_session_bytes_per_iteration.argtypes = [vp]
+    lib.topolow_session_stage.restype = C.c_int
+    lib.topolow_session_stage.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                          C.c_char_p, C.c_size_t]
+    lib.topolow_session_edge_error.restype = C.c_int
+    lib.topolow_session_edge_error.argtypes = [vp, vp, dp, C.POINTER(C.c_int64), C.c_char_p,
+                                               C.c_size_t]
+    lib.topolow_slab_plan.restype = C.c_int32
+    lib.topolow_slab_plan.argtypes = [C.c_int32, C.c_int32, C.c_uint64, C.c_int32, ip, C.c_int32]
+    lib.topolow_slab_stages_for_k.restype = C.c_int32
+    lib.topolow_slab_stages_for_k.argtypes = [C.c_double]
+    lib.topolow_gs_pair_order.restype = C.c_int64
+    lib.topolow_gs_pair_order.argtypes = [C.c_int32, C.c_uint64, C.c_int32, ip]
+    lib.topolow_encode_target.restype = C.c_uint32
+    lib.topolow_encode_target.argtypes = [C.c_double, C.c_int32]
+    lib.topolow_decode_target.restype = C.c_double
+    lib.topolow_decode_target.argtypes = [C.c_uint32, ip]
+    lib.topolow_controller_script.restype = C.c_int
+    lib.topolow_controller_script.argtypes = [dp, ip, dp, C.c_int32, C.c_double, C.c_int32,
+                                              C.c_double, ip, ip, dp, dp, ip]
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64F(a):
+    return np.require(np.asarray(a, dtype=np.float64), requirements=["F", "A"])
+
+
+def _i32F(a):
+    return np.require(np.asarray(a, dtype=np.int32), requirements=["F", "A"])
+
+
+def _check(rc: int, err) -> None:
+    if rc != OK:
+        raise NativeError(rc, err.value.decode(errors="replace") or f"libtopolow_relax error {rc}")
+
+
+def make_options(**kw) -> TopolowOptions:
+    lib = load()
+    o = TopolowOptions()
+    lib.topolow_default_options(C.byref(o))
+    cfg = dict(options)
+    cfg.update({k: v for k, v in kw.items() if v is not None})
+    seed = cfg.get("seed")
+    if seed is None:
+        seed = int(_host_rng.integers(0, 2 ** 63 - 1))
+    o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    sch = cfg.get("schedule", "auto")
+    o.schedule = _SCHEDULES[sch] if isinstance(sch, str) else int(sch)
+    pr = cfg.get("precision", "auto")
+    o.precision = _PRECISIONS[pr] if isinstance(pr, str) else int(pr)
+    o.slab_stages = int(cfg.get("slab_stages", 0) or 0)
+    o.device = int(cfg.get("device", -1))
+    o.gs_max_n = int(cfg.get("gs_max_n", 0) or 0)
+    return o
+
+
+@dataclass
+class NativeResult:
+    positions: np.ndarray
+    converged: bool
+    iterations: int
+    final_mae: float
+    final_k: float
+    info: Dict[str, Any] = field(default_factory=dict)
+
+
+def optimize_layout_exact_arrays(initial_positions, dissimilarity_matrix, threshold_matrix,
+                                 degrees, edge_i, edge_j, edge_dist, edge_thresh, n_iter, k0,
+                                 cooling_rate, c_repulsion, relative_epsilon, convergence_window,
+                                 convergence_check_freq, verbose=False, **opt_kw) -> NativeResult:
+    """`optimize_layout_exact_cpp(...)` (reference src/optimization.cpp:109-126) on the GPU."""
+    lib = load()
+    pos0 = _f64F(initial_positions)
+    n, dim = pos0.shape
+    D = _f64F(dissimilarity_matrix)
+    T = _i32F(threshold_matrix)
+    deg = np.ascontiguousarray(degrees, dtype=np.int32)
+    ei = np.ascontiguousarray(edge_i, dtype=np.int32)
+    ej = np.ascontiguousarray(edge_j, dtype=np.int32)
+    ed = np.ascontiguousarray(edge_dist, dtype=np.float64)
+    et = np.ascontiguousarray(edge_thresh, dtype=np.int32)
+    out = np.zeros((n, dim), dtype=np.float64, order="F")
+    conv, iters = C.c_int32(0), C.c_int32(0)
+    fmae, fk = C.c_double(0.0), C.c_double(0.0)
+    stats = TopolowRunStats()
+    err = C.create_string_buffer(512)
+    opt = make_options(**opt_kw)
+    rc = lib.topolow_optimize_layout_exact(
+        _dp(pos0), n, dim, _dp(D), _ip(T), _ip(deg), _ip(ei), _ip(ej), _dp(ed), _ip(et),
+        int(ei.shape[0]), int(n_iter), float(k0), float(cooling_rate), float(c_repulsion),
+        float(relative_epsilon), int(convergence_window), int(convergence_check_freq),
+        int(bool(verbose)), C.byref(opt), _dp(out), C.byref(conv), C.byref(iters), C.byref(fmae),
+        C.byref(fk), C.byref(stats), err, len(err))
+    _check(rc, err)
+    info = dict(schedule={SCHEDULE_SLAB: "slab", SCHEDULE_GS: "gs"}.get(stats.schedule_used),
+                precision={PRECISION_F32: "f32", PRECISION_F64: "f64"}.get(stats.precision_used),
+                iterations_run=stats.iterations_run, n_checks=stats.n_checks,
+                device_seconds=stats.device_seconds, total_seconds=stats.total_seconds,
+                stage_launches=stats.stage_launches, seed=int(opt.seed))
+    return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value),
+                        float(fmae.value), float(fk.value), info)
+
+
+def optimize_layout_exact(call) -> NativeResult:
+    """Takes a core.LayoutCall."""
+    return optimize_layout_exact_arrays(
+        call.initial_positions, call.dissimilarity_matrix, call.threshold_matrix, call.degrees,
+        call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.n_iter, call.k0,
+        call.cooling_rate, call.c_repulsion, call.relative_epsilon, call.convergence_window,
+        call.convergence_check_freq, call.verbose)
+
+
+def est_distances(positions) -> np.ndarray:
+    """as.matrix(dist(positions)) (reference R/core.R:474) on the GPU."""
+    lib = load()
+    pos = _f64F(positions)
+    n, dim = pos.shape
+    out = np.empty((n, n), dtype=np.float64)
+    err = C.create_string_buffer(512)
+    rc = lib.topolow_est_distances(_dp(pos), n, dim, _dp(out), int(options.get("device", -1)),
+                                   err, len(err))
+    _check(rc, err)
+    return out
+
+
+# ---- host-side helpers (no GPU needed) ---------------------------------------------------
+def slab_plan(n: int, slab_stages: int, seed: int, it: int) -> np.ndarray:
+    lib = load()
+    buf = np.zeros((64, 4), dtype=np.int32)
+    ns = lib.topolow_slab_plan(int(n), int(slab_stages), int(seed), int(it), _ip(buf), 64)
+    return buf[:ns].copy()
+
+
+def slab_stages_for_k(k: float) -> int:
+    return int(load().topolow_slab_stages_for_k(float(k)))
+
+
+def gs_pair_order(n: int, seed: int, it: int) -> np.ndarray:
+    lib = load()
+    buf = np.zeros((n * (n - 1) // 2, 2), dtype=np.int32)
+    cnt = lib.topolow_gs_pair_order(int(n), int(seed), int(it), _ip(buf))
+    assert cnt == buf.shape[0]
+    return buf
+
+
+def encode_target(d: float, code: int) -> int:
+    return int(load().topolow_encode_target(float(d), int(code)))
+
+
+def decode_target(bits: int):
+    c = C.c_int32(0)
+    v = load().topolow_decode_target(int(bits), C.byref(c))
+    return float(v), int(c.value)
+
+
+def controller_script(mae_seq, iter_seq, k_seq, k0, window, eps):
+    lib = load()
+    m = np.ascontiguousarray(mae_seq, dtype=np.float64)
+    it = np.ascontiguousarray(iter_seq, dtype=np.int32)
+    ks = np.ascontiguousarray(k_seq, dtype=np.float64)
+    n = int(m.shape[0])
+    stopped = C.c_int32(-1)
+    snaps = np.zeros(n, dtype=np.int32)
+    bm, bk, bi = C.c_double(0), C.c_double(0), C.c_int32(0)
+    lib.topolow_controller_script(_dp(m), _ip(it), _dp(ks), n, float(k0), int(window), float(eps),
+                                  C.byref(stopped), _ip(snaps), C.byref(bm), C.byref(bk),
+                                  C.byref(bi))
+    return dict(stopped_at=int(stopped.value), snapshots=snaps.astype(bool),
+                best_mae=float(bm.value), best_k=float(bk.value), best_iter=int(bi.value))
+
+
+class Session:
+    """Device-resident slab session (include/topolow_relax.h, `topolow_session_*`)."""
+
+    def __init__(self, n, ndim, row_begin=0, row_end=None, precision="f32", device=-1):
+        self.lib = load()
+        self.n, self.ndim = int(n), int(ndim)
+        self.row_begin = int(row_begin)
+        self.row_end = int(n if row_end is None else row_end)
+        self.precision = precision
+        self._h = C.c_void_p(None)
+        self._err = C.create_string_buffer(512)
+        rc = self.lib.topolow_session_create(C.byref(self._h), self.n, self.ndim, self.row_begin,
+                                             self.row_end, _PRECISIONS[precision], int(device),
+                                             self._err, len(self._err))
+        _check(rc, self._err)
+
+    def close(self):
+        if self._h:
+            self.lib.topolow_session_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_dense(self, D, T, degrees):
+        D, T = _f64F(D), _i32F(T)
+        deg = np.ascontiguousarray(degrees, dtype=np.int32)
+        _check(self.lib.topolow_session_load_dense(self._h, _dp(D), _ip(T), _ip(deg), self._err,
+                                                   len(self._err)), self._err)
+
+    def load_coo(self, ei, ej, ed, et, degrees):
+        ei = np.ascontiguousarray(ei, dtype=np.int32)
+        ej = np.ascontiguousarray(ej, dtype=np.int32)
+        ed = np.ascontiguousarray(ed, dtype=np.float64)
+        et = np.ascontiguousarray(et, dtype=np.int32)
+        deg = np.ascontiguousarray(degrees, dtype=np.int32)
+        _check(self.lib.topolow_session_load_coo(self._h, _ip(ei), _ip(ej), _dp(ed), _ip(et),
+                                                 int(ei.shape[0]), _ip(deg), self._err,
+                                                 len(self._err)), self._err)
+
+    def set_edges(self, ei, ej, ed, et):
+        ei = np.ascontiguousarray(ei, dtype=np.int32)
+        ej = np.ascontiguousarray(ej, dtype=np.int32)
+        ed = np.ascontiguousarray(ed, dtype=np.float64)
+        et = np.ascontiguousarray(et, dtype=np.int32)
+        _check(self.lib.topolow_session_set_edges(self._h, _ip(ei), _ip(ej), _dp(ed), _ip(et),
+                                                  int(ei.shape[0]), self._err, len(self._err)),
+               self._err)
+
+    def set_positions(self, pos):
+        pos = _f64F(pos)
+        assert pos.shape == (self.n, self.ndim)
+        _check(self.lib.topolow_session_set_positions(self._h, _dp(pos), self._err,
+                                                      len(self._err)), self._err)
+
+    def get_positions(self):
+        out = np.zeros((self.n, self.ndim), dtype=np.float64, order="F")
+        _check(self.lib.topolow_session_get_positions(self._h, _dp(out), self._err,
+                                                      len(self._err)), self._err)
+        return np.ascontiguousarray(out)
+
+    def begin(self, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon=1e-4,
+              convergence_window=5, convergence_check_freq=3, seed=0, slab_stages=0):
+        _check(self.lib.topolow_session_begin(
+            self._h, int(n_iter), float(k0), float(cooling_rate), float(c_repulsion),
+            float(relative_epsilon), int(convergence_window), int(convergence_check_freq),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, int(slab_stages), self._err, len(self._err)), self._err)
+
+    def enqueue(self, max_iters) -> int:
+        enq = C.c_int32(0)
+        _check(self.lib.topolow_session_enqueue(self._h, int(max_iters), C.byref(enq), self._err,
+                                                len(self._err)), self._err)
+        return int(enq.value)
+
+    def sync(self):
+        it, st, mae = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+        _check(self.lib.topolow_session_sync(self._h, C.byref(it), C.byref(st), C.byref(mae),
+                                             self._err, len(self._err)), self._err)
+        return int(it.value), bool(st.value), float(mae.value)
+
+    def finish(self) -> NativeResult:
+        out = np.zeros((self.n, self.ndim), dtype=np.float64, order="F")
+        conv, iters = C.c_int32(0), C.c_int32(0)
+        fmae, fk = C.c_double(0.0), C.c_double(0.0)
+        _check(self.lib.topolow_session_finish(self._h, _dp(out), C.byref(conv), C.byref(iters),
+                                               C.byref(fmae), C.byref(fk), self._err,
+                                               len(self._err)), self._err)
+        return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value),
+                            float(fmae.value), float(fk.value))
+
+    def run(self, chunk=64):
+        while self.enqueue(chunk) > 0:
+            pass
+        return self.sync()
+
+    def set_profiling(self, enable: bool):
+        self.lib.topolow_session_set_profiling(self._h, int(bool(enable)))
+
+    def profile(self):
+        """(stage_ms, stage_launches, check_ms, checks) since profiling was enabled."""
+        sm, cm = C.c_double(0.0), C.c_double(0.0)
+        sl, cl = C.c_int64(0), C.c_int64(0)
+        _check(self.lib.topolow_session_profile(self._h, C.byref(sm), C.byref(sl), C.byref(cm),
+                                                C.byref(cl), self._err, len(self._err)), self._err)
+        return float(sm.value), int(sl.value), float(cm.value), int(cl.value)
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.topolow_session_stream(self._h) or 0)
+
+    @property
+    def stage_launches(self) -> int:
+        return int(self.lib.topolow_session_stage_launches(self._h))
+
+    @property
+    def bytes_per_iteration(self) -> int:
+        return int(self.lib.topolow_session_bytes_per_iteration(self._h))
+
+    def stage(self, d_pos_in: int, d_pos_out: int, it: int, stage: int, n_stages: int, k: float):
+        _check(self.lib.topolow_session_stage(self._h, C.c_void_p(d_pos_in), C.c_void_p(d_pos_out),
+                                              int(it), int(stage), int(n_stages), float(k),
+                                              self._err, len(self._err)), self._err)
+
+    def edge_error(self, d_pos: int):
+        s, c = C.c_double(0.0), C.c_int64(0)
+        _check(self.lib.topolow_session_edge_error(self._h, C.c_void_p(d_pos), C.byref(s),
+                                                   C.byref(c), self._err, len(self._err)), self._err)
+        return float(s.value), int(c.value)

@@ -1,0 +1,183 @@
+// topolow_amd/csrc/relax_common.h -- shared host/device definitions of libtopolow_relax.so.
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TL_HD __host__ __device__
+#else
+#define TL_HD
+#endif
+
+namespace topolow {
+
+// ---------------------------------------------------------------------------------------
+// fp32 target encoding.  One 4-byte word per ORDERED pair (row i, column c):
+//   value  = fp32(target) rounded to a multiple of 4 ulp (relative error < 3e-7)
+//   bits[1:0] = threshold code: 0 exact, 1 ">", 2 "<", 3 skip (diagonal, padding)
+//   +Inf (code 0) = unmeasured pair -> repulsion (reference src/optimization.cpp:221,269-281)
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kCodeMask = 3u;
+constexpr uint32_t kSkipWord = 3u;           // 0.0f | skip
+constexpr uint32_t kInfWord = 0x7f800000u;   // +Inf | exact  == unmeasured
+
+TL_HD inline uint32_t f32_bits(float f) {
+  union { float f; uint32_t u; } v; v.f = f; return v.u;
+}
+TL_HD inline float bits_f32(uint32_t u) {
+  union { float f; uint32_t u; } v; v.u = u; return v.f;
+}
+
+// threshold_code as the reference passes it: 0 exact, 1 ">", anything else "<" (the
+// reference's else-branch, src/optimization.cpp:236-242).
+TL_HD inline uint32_t encode_target(double t, int code) {
+  if (!__builtin_isfinite(t)) return kInfWord;  // NaN, +-Inf: not finite -> unmeasured (:221)
+  float f = (float)t;
+  uint32_t u = f32_bits(f);
+  uint32_t mag = u & 0x7fffffffu;
+  if (mag >= 0x7f7ffffcu) mag = 0x7f7ffffcu;  // keep huge finite targets finite
+  else mag = (mag + 2u) & ~kCodeMask;
+  if (mag >= 0x7f800000u) mag = 0x7f7ffffcu;
+  const uint32_t c = code == 0 ? 0u : (code == 1 ? 1u : 2u);
+  return (u & 0x80000000u) | mag | c;
+}
+
+TL_HD inline double decode_target(uint32_t w, int* code) {
+  const uint32_t c = w & kCodeMask;
+  if (code) *code = c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? -1 : 3));
+  return (double)bits_f32(w & ~kCodeMask);
+}
+
+// ---------------------------------------------------------------------------------------
+// Counter-based random numbers for schedules (same stream on host and device).
+// ---------------------------------------------------------------------------------------
+TL_HD inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+TL_HD inline uint64_t rnd64(uint64_t seed, uint64_t stream, uint64_t ctr) {
+  return mix64(mix64(seed ^ (stream * 0xd1342543de82ef95ull)) + ctr * 0x9e3779b97f4a7c15ull);
+}
+// Unbiased-enough bounded integer (multiply-shift on the high 32 bits).
+TL_HD inline uint32_t rnd_below(uint64_t r, uint32_t bound) {
+  return (uint32_t)(((r >> 32) * (uint64_t)bound) >> 32);
+}
+
+// ---------------------------------------------------------------------------------------
+// Slab plan.  Columns live in the padded index space [0, n4), n4 = roundup(n, 4) (padding
+// columns carry the skip code).  An iteration is cut into S' = ceil(n4 / w) slabs of width
+// w = roundup(ceil(n4 / S), 4) placed cyclically from a random offset (multiple of 4), and
+// executed in a random order.  A slab that wraps is two ranges.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxStages = 64;
+
+struct SlabGeom {
+  int n4;
+  int w;
+  int n_stages;
+};
+
+TL_HD inline SlabGeom slab_geom(int n, int stages) {
+  SlabGeom g;
+  g.n4 = (n + 3) & ~3;
+  if (stages < 1) stages = 1;
+  if (stages > kMaxStages) stages = kMaxStages;
+  int w = (g.n4 + stages - 1) / stages;
+  w = (w + 3) & ~3;
+  if (w < 4) w = 4;
+  g.w = w;
+  g.n_stages = (g.n4 + w - 1) / w;
+  return g;
+}
+
+struct SlabRanges {
+  int b0, e0, b1, e1;  // [b0,e0) and [b1,e1) (second empty unless wrapped)
+};
+
+// Range(s) of the slab executed at position `slot` of iteration `iter`.
+TL_HD inline SlabRanges slab_ranges(const SlabGeom& g, uint64_t seed, int iter, int slot) {
+  // random order: Fisher-Yates over stage ids, recomputed by every caller (<= 64 steps)
+  int perm[kMaxStages];
+  for (int q = 0; q < g.n_stages; ++q) perm[q] = q;
+  for (int q = g.n_stages - 1; q > 0; --q) {
+    const uint32_t r = rnd_below(rnd64(seed, 0x51ab5ull, ((uint64_t)iter << 8) | (uint64_t)q),
+                                 (uint32_t)(q + 1));
+    const int tmp = perm[q]; perm[q] = perm[r]; perm[r] = tmp;
+  }
+  const int j = perm[slot];
+  const uint32_t groups = (uint32_t)(g.n4 / 4);
+  const int off = 4 * (int)rnd_below(rnd64(seed, 0x0ff5e7ull, (uint64_t)iter), groups);
+  const int len = (j == g.n_stages - 1) ? (g.n4 - j * g.w) : g.w;
+  int start = off + j * g.w;
+  if (start >= g.n4) start -= g.n4;
+  SlabRanges r;
+  r.b0 = start;
+  if (start + len <= g.n4) { r.e0 = start + len; r.b1 = 0; r.e1 = 0; }
+  else { r.e0 = g.n4; r.b1 = 0; r.e1 = start + len - g.n4; }
+  return r;
+}
+
+// Adaptive stage count: stable for k/S <~ 5 in the schedule study (tests/study), used with a
+// 2x margin; never fewer than 4 stages.
+TL_HD inline int slab_stages_for_k(double k) {
+  int s = 4;
+  while ((double)s * 2.5 < k && s < kMaxStages) s <<= 1;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// Convergence controller (reference src/optimization.cpp:168-179 state, :303-357 logic).
+// ---------------------------------------------------------------------------------------
+struct Controller {
+  double best_mae;
+  double best_k;
+  double eps;
+  int best_iter;
+  int worsening;
+  int plateau;
+  int window;
+
+  TL_HD void init(double k0, int window_, double eps_) {
+    best_mae = DBL_MAX; best_k = k0; eps = eps_; best_iter = 0; worsening = 0; plateau = 0;
+    window = window_;
+  }
+  // Returns bit0 = stop, bit1 = snapshot positions now.
+  TL_HD int observe(double err, int iter1, double k) {
+    int snap = 0;
+    if (err < best_mae * (1.0 - eps)) {
+      best_mae = err; best_k = k; best_iter = iter1; worsening = 0; plateau = 0;
+      return 2;
+    }
+    if (err <= best_mae * (1.0 + eps)) {
+      if (err < best_mae) { best_mae = err; best_k = k; best_iter = iter1; snap = 2; }
+      worsening = 0;
+      ++plateau;
+      return snap | (plateau >= window ? 1 : 0);
+    }
+    plateau = 0;  // also the NaN path: every comparison above is false
+    ++worsening;
+    return worsening >= window ? 1 : 0;
+  }
+};
+
+// Device-resident run state of one embedding (slab path).
+struct RunState {
+  Controller ctl;
+  double k_base;        // spring constant at iteration iter_base
+  double cooling;
+  double last_mae;
+  int iter_base;        // iterations completed
+  int n_iter;
+  int stopped;          // 1 after the controller said stop (kernels become no-ops)
+  int converged;
+  int n_checks;
+  int first_nonfinite;  // first iteration (1-based) that produced a non-finite position
+  int pad0, pad1;
+};
+
+}  // namespace topolow

@@ -1,0 +1,886 @@
+// topolow_amd/csrc/topolow_relax.hip -- host side of libtopolow_relax.so: the C ABI of
+// include/topolow_relax.h over the HIP kernels in relax_kernels.h / relax_gs.h.
+//
+// Replaces the native half of the reference's euclidean_embedding():
+//   .Call(`_topolow_optimize_layout_exact_cpp`, ...)  (reference R/RcppExports.R:4-6)
+//   -> optimize_layout_exact_cpp                       (reference src/optimization.cpp:109-382)
+// There is no CPU fallback in this library: without a HIP device every entry point that
+// computes returns TOPOLOW_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/topolow_relax.h"
+#include "relax_common.h"
+#include "relax_kernels.h"
+#include "relax_gs.h"
+
+using namespace topolow;
+
+namespace {
+
+constexpr int kMaxDim = 10;
+constexpr int kDefaultGsMaxN = 1024;
+
+struct HipError {
+  int code;
+  std::string msg;
+};
+
+void set_err(char* errbuf, size_t errlen, const char* fmt, ...) {
+  if (!errbuf || errlen == 0) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(errbuf, errlen, fmt, ap);
+  va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      throw HipError{e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice              \
+                         ? TOPOLOW_ERR_NO_DEVICE                                        \
+                         : TOPOLOW_ERR_HIP,                                             \
+                     std::string(#expr) + ": " + hipGetErrorString(e_)};                \
+    }                                                                                   \
+  } while (0)
+
+int select_device(int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    throw HipError{TOPOLOW_ERR_NO_DEVICE,
+                   "no HIP device available (libtopolow_relax has no CPU fallback)"};
+  if (device < 0) {
+    HIP_TRY(hipGetDevice(&device));
+  } else {
+    if (device >= count) throw HipError{TOPOLOW_ERR_NO_DEVICE, "HIP device ordinal out of range"};
+    HIP_TRY(hipSetDevice(device));
+  }
+  return device;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+  }
+  void release() {
+    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+  }
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch())
+      .count();
+}
+
+}  // namespace
+
+// =========================================================================================
+// Session (slab path)
+// =========================================================================================
+struct topolow_session {
+  int n = 0, dim = 0, row_begin = 0, row_end = 0, ld = 0;
+  int precision = TOPOLOW_PRECISION_F32;
+  int device = 0;
+  hipStream_t stream = nullptr;
+
+  DevBuf<uint32_t> enc;
+  DevBuf<float> gplus;
+  DevBuf<unsigned char> pos[2];
+  DevBuf<unsigned char> best;
+  DevBuf<int> ei, ej;
+  DevBuf<unsigned char> et;
+  DevBuf<int8_t> ec;
+  long long n_edges = 0;
+  int n_parts = 0;
+  DevBuf<double> part_sum;
+  DevBuf<unsigned long long> part_cnt;
+  DevBuf<RunState> state;
+  RunState* mailbox = nullptr;      // pinned host memory
+  RunState* mailbox_dev = nullptr;  // device alias of mailbox
+
+  // run parameters
+  int n_iter = 0, check_freq = 3, window = 5, fixed_stages = 0;
+  double k0 = 0, cooling = 0, c_rep = 0, eps = 1e-4;
+  uint64_t seed = 0;
+  // host-side progress
+  int iters_enqueued = 0;
+  double k_host = 0;
+  int cur = 0;
+  bool host_seen_stop = false;
+  bool began = false;
+  long long stage_launches = 0;
+  std::deque<hipEvent_t> pending;
+  std::vector<hipEvent_t> event_pool;
+  // profiling (roofline accounting)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_stage, prof_check;
+
+  size_t real_size() const { return precision == TOPOLOW_PRECISION_F64 ? 8 : 4; }
+  int rows() const { return row_end - row_begin; }
+
+  ~topolow_session() {
+    for (auto& pr : prof_stage) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : prof_check) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : pending) (void)hipEventDestroy(e);
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+    if (mailbox) (void)hipHostFree(mailbox);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+// ---- kernel dispatch over (DIM, real) ----------------------------------------------------
+#define TL_DISPATCH_DIM(dim, FN, ...)                 \
+  switch (dim) {                                      \
+    case 1: FN<1>(__VA_ARGS__); break;                \
+    case 2: FN<2>(__VA_ARGS__); break;                \
+    case 3: FN<3>(__VA_ARGS__); break;                \
+    case 4: FN<4>(__VA_ARGS__); break;                \
+    case 5: FN<5>(__VA_ARGS__); break;                \
+    case 6: FN<6>(__VA_ARGS__); break;                \
+    case 7: FN<7>(__VA_ARGS__); break;                \
+    case 8: FN<8>(__VA_ARGS__); break;                \
+    case 9: FN<9>(__VA_ARGS__); break;                \
+    case 10: FN<10>(__VA_ARGS__); break;              \
+    default: throw HipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 10"}; \
+  }
+
+struct ProfScope {
+  topolow_session* s;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>>* dst;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(topolow_session* s_, std::vector<std::pair<hipEvent_t, hipEvent_t>>* d) : s(s_), dst(d) {
+    if (!s->profiling) return;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, s->stream));
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, s->stream);
+    dst->emplace_back(a, b);
+  }
+};
+
+template <int DIM>
+void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st, SlabRanges rg,
+                  int iter1, double k) {
+  const int blocks = (s->rows() + kRowsPerWG - 1) / kRowsPerWG;
+  if (blocks <= 0) return;
+  ProfScope prof(s, &s->prof_stage);
+  if (s->precision == TOPOLOW_PRECISION_F64) {
+    hipLaunchKernelGGL((slab_stage_kernel<DIM, double>), dim3(blocks), dim3(kThreads), 0,
+                       s->stream, s->enc.p, s->ld, s->row_begin, s->row_end, s->n,
+                       (const double*)pin, (double*)pout, s->gplus.p, st, rg, iter1, k, s->c_rep);
+  } else {
+    hipLaunchKernelGGL((slab_stage_kernel<DIM, float>), dim3(blocks), dim3(kThreads), 0,
+                       s->stream, s->enc.p, s->ld, s->row_begin, s->row_end, s->n,
+                       (const float*)pin, (float*)pout, s->gplus.p, st, rg, iter1, k, s->c_rep);
+  }
+  HIP_TRY(hipGetLastError());
+  s->stage_launches += 1;
+}
+
+template <int DIM>
+void launch_edge_error(topolow_session* s, const void* pos, const RunState* st) {
+  if (s->precision == TOPOLOW_PRECISION_F64) {
+    hipLaunchKernelGGL((edge_error_kernel<DIM, double, double>), dim3(s->n_parts),
+                       dim3(kThreads), 0, s->stream, (const double*)pos, s->ei.p, s->ej.p,
+                       (const double*)s->et.p, s->ec.p, s->n_edges, s->part_sum.p,
+                       s->part_cnt.p, st);
+  } else {
+    hipLaunchKernelGGL((edge_error_kernel<DIM, float, float>), dim3(s->n_parts), dim3(kThreads),
+                       0, s->stream, (const float*)pos, s->ei.p, s->ej.p, (const float*)s->et.p,
+                       s->ec.p, s->n_edges, s->part_sum.p, s->part_cnt.p, st);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+void launch_controller(topolow_session* s, const void* pos, int iter1, double k_after) {
+  const long long nv = (long long)s->n * s->dim;
+  if (s->precision == TOPOLOW_PRECISION_F64) {
+    hipLaunchKernelGGL((controller_kernel<double>), dim3(1), dim3(kThreads), 0, s->stream,
+                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, s->n_parts,
+                       (const double*)pos, (double*)s->best.p, nv, iter1, k_after);
+  } else {
+    hipLaunchKernelGGL((controller_kernel<float>), dim3(1), dim3(kThreads), 0, s->stream,
+                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, s->n_parts,
+                       (const float*)pos, (float*)s->best.p, nv, iter1, k_after);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+// positions host (n x dim f64 column-major) <-> device (n x dim row-major, session precision)
+void upload_positions(topolow_session* s, const double* host_colmajor, void* dst) {
+  const size_t nv = (size_t)s->n * s->dim;
+  if (s->precision == TOPOLOW_PRECISION_F64) {
+    std::vector<double> tmp(nv);
+    for (int i = 0; i < s->n; ++i)
+      for (int d = 0; d < s->dim; ++d) tmp[(size_t)i * s->dim + d] = host_colmajor[i + (size_t)d * s->n];
+    HIP_TRY(hipMemcpyAsync(dst, tmp.data(), nv * 8, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  } else {
+    std::vector<float> tmp(nv);
+    for (int i = 0; i < s->n; ++i)
+      for (int d = 0; d < s->dim; ++d)
+        tmp[(size_t)i * s->dim + d] = (float)host_colmajor[i + (size_t)d * s->n];
+    HIP_TRY(hipMemcpyAsync(dst, tmp.data(), nv * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+}
+
+void download_positions(topolow_session* s, const void* src, double* host_colmajor) {
+  const size_t nv = (size_t)s->n * s->dim;
+  if (s->precision == TOPOLOW_PRECISION_F64) {
+    std::vector<double> tmp(nv);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), src, nv * 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < s->n; ++i)
+      for (int d = 0; d < s->dim; ++d) host_colmajor[i + (size_t)d * s->n] = tmp[(size_t)i * s->dim + d];
+  } else {
+    std::vector<float> tmp(nv);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), src, nv * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < s->n; ++i)
+      for (int d = 0; d < s->dim; ++d)
+        host_colmajor[i + (size_t)d * s->n] = (double)tmp[(size_t)i * s->dim + d];
+  }
+}
+
+void upload_degrees(topolow_session* s, const int32_t* degrees) {
+  std::vector<float> g(s->n);
+  for (int i = 0; i < s->n; ++i) g[i] = (float)degrees[i] + 1.0f;  // reference :137-140
+  s->gplus.alloc(s->n);
+  HIP_TRY(hipMemcpy(s->gplus.p, g.data(), (size_t)s->n * 4, hipMemcpyHostToDevice));
+}
+
+hipEvent_t take_event(topolow_session* s) {
+  if (!s->event_pool.empty()) {
+    hipEvent_t e = s->event_pool.back();
+    s->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+
+void poll_checks(topolow_session* s, size_t keep_in_flight) {
+  while (s->pending.size() > keep_in_flight) {
+    hipEvent_t e = s->pending.front();
+    HIP_TRY(hipEventSynchronize(e));
+    s->pending.pop_front();
+    s->event_pool.push_back(e);
+    if (s->mailbox->stopped) s->host_seen_stop = true;
+  }
+  // opportunistic: anything already finished
+  while (!s->pending.empty() && hipEventQuery(s->pending.front()) == hipSuccess) {
+    s->event_pool.push_back(s->pending.front());
+    s->pending.pop_front();
+    if (s->mailbox->stopped) s->host_seen_stop = true;
+  }
+}
+
+template <typename F>
+int guarded(char* errbuf, size_t errlen, F&& body) {
+  try {
+    body();
+    return TOPOLOW_OK;
+  } catch (const HipError& e) {
+    set_err(errbuf, errlen, "%s", e.msg.c_str());
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    set_err(errbuf, errlen, "out of host memory");
+    return TOPOLOW_ERR_HIP;
+  }
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* topolow_relax_version(void) { return "topolow_relax 0.1 (gfx950)"; }
+
+void topolow_default_options(topolow_options* opt) {
+  if (!opt) return;
+  std::memset(opt, 0, sizeof(*opt));
+  opt->seed = 0;
+  opt->schedule = TOPOLOW_SCHEDULE_AUTO;
+  opt->precision = TOPOLOW_PRECISION_AUTO;
+  opt->slab_stages = 0;
+  opt->device = -1;
+  opt->gs_max_n = 0;
+}
+
+uint32_t topolow_encode_target(double dissimilarity, int32_t threshold_code) {
+  return encode_target(dissimilarity, threshold_code);
+}
+double topolow_decode_target(uint32_t bits, int32_t* threshold_code) {
+  int c = 0;
+  const double v = decode_target(bits, &c);
+  if (threshold_code) *threshold_code = c;
+  return v;
+}
+
+int32_t topolow_slab_stages_for_k(double k) { return slab_stages_for_k(k); }
+
+int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t iter,
+                          int32_t* ranges_out, int32_t max_stages) {
+  const SlabGeom g = slab_geom(n, slab_stages);
+  if (!ranges_out) return g.n_stages;
+  for (int slot = 0; slot < g.n_stages && slot < max_stages; ++slot) {
+    const SlabRanges r = slab_ranges(g, seed, iter, slot);
+    ranges_out[4 * slot + 0] = r.b0;
+    ranges_out[4 * slot + 1] = r.e0;
+    ranges_out[4 * slot + 2] = r.b1;
+    ranges_out[4 * slot + 3] = r.e1;
+  }
+  return g.n_stages;
+}
+
+int64_t topolow_gs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_t* pairs_out) {
+  return gs_pair_order(n, seed, iter, pairs_out);
+}
+
+int topolow_controller_script(const double* mae_seq, const int32_t* iter_seq,
+                              const double* k_seq, int32_t n_obs, double k0, int32_t window,
+                              double eps, int32_t* stopped_at_obs, int32_t* snapshot_flags,
+                              double* best_mae, double* best_k, int32_t* best_iter) {
+  Controller c;
+  c.init(k0, window, eps);
+  *stopped_at_obs = -1;
+  for (int o = 0; o < n_obs; ++o) {
+    const int a = c.observe(mae_seq[o], iter_seq[o], k_seq[o]);
+    if (snapshot_flags) snapshot_flags[o] = (a & 2) ? 1 : 0;
+    if (a & 1) { *stopped_at_obs = o; break; }
+  }
+  *best_mae = c.best_mae;
+  *best_k = c.best_k;
+  *best_iter = c.best_iter;
+  return TOPOLOW_OK;
+}
+
+// ---- session ---------------------------------------------------------------------------
+int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32_t row_begin,
+                           int32_t row_end, int32_t precision, int32_t device, char* errbuf,
+                           size_t errlen) {
+  if (!out) return TOPOLOW_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  if (n < 2) {
+    set_err(errbuf, errlen, "Need at least 2 points for embedding");
+    return TOPOLOW_ERR_TOO_FEW_POINTS;
+  }
+  if (ndim < 1 || ndim > kMaxDim) {
+    set_err(errbuf, errlen, "ndim must be between 1 and %d in this build", kMaxDim);
+    return TOPOLOW_ERR_UNSUPPORTED;
+  }
+  if (row_begin < 0 || row_end > n || row_begin >= row_end) {
+    set_err(errbuf, errlen, "bad row block [%d,%d) for n=%d", row_begin, row_end, n);
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  }
+  topolow_session* s = nullptr;
+  const int rc = guarded(errbuf, errlen, [&] {
+    const int dev = select_device(device);
+    s = new topolow_session();
+    s->device = dev;
+    s->n = n;
+    s->dim = ndim;
+    s->row_begin = row_begin;
+    s->row_end = row_end;
+    s->ld = (n + 63) & ~63;
+    s->precision = precision == TOPOLOW_PRECISION_F64 ? TOPOLOW_PRECISION_F64
+                                                      : TOPOLOW_PRECISION_F32;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->enc.alloc((size_t)s->rows() * s->ld);
+    const size_t pos_bytes = (size_t)n * ndim * s->real_size();
+    s->pos[0].alloc(pos_bytes);
+    s->pos[1].alloc(pos_bytes);
+    s->best.alloc(pos_bytes);
+    s->state.alloc(1);
+    HIP_TRY(hipHostMalloc((void**)&s->mailbox, sizeof(RunState), hipHostMallocMapped));
+    std::memset(s->mailbox, 0, sizeof(RunState));
+    HIP_TRY(hipHostGetDevicePointer((void**)&s->mailbox_dev, s->mailbox, 0));
+  });
+  if (rc != TOPOLOW_OK) { delete s; return rc; }
+  *out = s;
+  return TOPOLOW_OK;
+}
+
+void topolow_session_destroy(topolow_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  delete s;
+}
+
+int topolow_session_load_dense(topolow_session* s, const double* D, const int32_t* T,
+                               const int32_t* degrees, char* errbuf, size_t errlen) {
+  if (!s || !D || !T || !degrees) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t nn = (size_t)s->n * s->n;
+    DevBuf<double> dD;
+    DevBuf<int> dT;
+    dD.alloc(nn);
+    dT.alloc(nn);
+    HIP_TRY(hipMemcpy(dD.p, D, nn * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dT.p, T, nn * 4, hipMemcpyHostToDevice));
+    dim3 grid((s->ld + kThreads - 1) / kThreads, s->rows());
+    hipLaunchKernelGGL(encode_dense_kernel, grid, dim3(kThreads), 0, s->stream, dD.p, dT.p, s->n,
+                       s->row_begin, s->row_end, s->ld, s->enc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    upload_degrees(s, degrees);
+  });
+}
+
+int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const int32_t* edge_j,
+                             const double* edge_dist, const int32_t* edge_thresh,
+                             int64_t n_edges, const int32_t* degrees, char* errbuf,
+                             size_t errlen) {
+  if (!s || !degrees || n_edges < 0) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    dim3 grid((s->ld + kThreads - 1) / kThreads, s->rows());
+    hipLaunchKernelGGL(fill_unmeasured_kernel, grid, dim3(kThreads), 0, s->stream, s->n,
+                       s->row_begin, s->row_end, s->ld, s->enc.p);
+    HIP_TRY(hipGetLastError());
+    const int64_t chunk = 1 << 24;
+    DevBuf<int> di, dj, dc;
+    DevBuf<double> dd;
+    const size_t cap = (size_t)std::min<int64_t>(chunk, std::max<int64_t>(n_edges, 1));
+    di.alloc(cap); dj.alloc(cap); dc.alloc(cap); dd.alloc(cap);
+    for (int64_t off = 0; off < n_edges; off += chunk) {
+      const int64_t m = std::min<int64_t>(chunk, n_edges - off);
+      HIP_TRY(hipMemcpyAsync(di.p, edge_i + off, m * 4, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(dj.p, edge_j + off, m * 4, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(dd.p, edge_dist + off, m * 8, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(dc.p, edge_thresh + off, m * 4, hipMemcpyHostToDevice, s->stream));
+      hipLaunchKernelGGL(scatter_edges_kernel, dim3((unsigned)((m + kThreads - 1) / kThreads)),
+                         dim3(kThreads), 0, s->stream, di.p, dj.p, dd.p, dc.p, (long long)m, s->n,
+                         s->row_begin, s->row_end, s->ld, s->enc.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    upload_degrees(s, degrees);
+  });
+}
+
+int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const int32_t* edge_j,
+                              const double* edge_dist, const int32_t* edge_thresh,
+                              int64_t n_edges, char* errbuf, size_t errlen) {
+  if (!s || n_edges < 0) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    s->n_edges = n_edges;
+    const size_t m = (size_t)n_edges;
+    s->ei.alloc(m); s->ej.alloc(m); s->ec.alloc(m);
+    std::vector<int8_t> codes(m);
+    for (size_t e = 0; e < m; ++e) {
+      const int c = edge_thresh[e];
+      codes[e] = (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : (c == -1 ? -1 : 2)));  // others never count
+    }
+    if (m) {
+      HIP_TRY(hipMemcpy(s->ei.p, edge_i, m * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->ej.p, edge_j, m * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->ec.p, codes.data(), m, hipMemcpyHostToDevice));
+    }
+    if (s->precision == TOPOLOW_PRECISION_F64) {
+      s->et.alloc(m * 8);
+      if (m) HIP_TRY(hipMemcpy(s->et.p, edge_dist, m * 8, hipMemcpyHostToDevice));
+    } else {
+      std::vector<float> t(m);
+      for (size_t e = 0; e < m; ++e) t[e] = (float)edge_dist[e];
+      s->et.alloc(m * 4);
+      if (m) HIP_TRY(hipMemcpy(s->et.p, t.data(), m * 4, hipMemcpyHostToDevice));
+    }
+    long long blocks = (n_edges + (long long)kThreads * 8 - 1) / ((long long)kThreads * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    s->n_parts = (int)blocks;
+    s->part_sum.alloc(s->n_parts);
+    s->part_cnt.alloc(s->n_parts);
+  });
+}
+
+int topolow_session_set_positions(topolow_session* s, const double* positions, char* errbuf,
+                                  size_t errlen) {
+  if (!s || !positions) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    s->cur = 0;
+    upload_positions(s, positions, s->pos[0].p);
+  });
+}
+
+int topolow_session_get_positions(topolow_session* s, double* positions, char* errbuf,
+                                  size_t errlen) {
+  if (!s || !positions) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    download_positions(s, s->pos[s->cur].p, positions);
+  });
+}
+
+int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double cooling_rate,
+                          double c_repulsion, double relative_epsilon,
+                          int32_t convergence_window, int32_t convergence_check_freq,
+                          uint64_t seed, int32_t slab_stages, char* errbuf, size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->gplus.p) throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "session has no targets loaded"};
+    if (!s->part_sum.p) throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "session has no edge list"};
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (hipEvent_t e : s->pending) s->event_pool.push_back(e);
+    s->pending.clear();
+    s->n_iter = n_iter;
+    s->k0 = k0;
+    s->cooling = cooling_rate;
+    s->c_rep = c_repulsion;
+    s->eps = relative_epsilon;
+    s->window = convergence_window;
+    s->check_freq = convergence_check_freq < 1 ? 10 : convergence_check_freq;  // reference :181
+    s->seed = seed;
+    s->fixed_stages = slab_stages;
+    s->iters_enqueued = 0;
+    s->k_host = k0;
+    s->host_seen_stop = false;
+    s->began = true;
+    RunState st;
+    std::memset(&st, 0, sizeof st);
+    st.ctl.init(k0, convergence_window, relative_epsilon);
+    st.k_base = k0;
+    st.cooling = cooling_rate;
+    st.n_iter = n_iter;
+    st.first_nonfinite = 0x7fffffff;
+    *s->mailbox = st;
+    HIP_TRY(hipMemcpyAsync(s->state.p, &st, sizeof st, hipMemcpyHostToDevice, s->stream));
+    // best snapshot starts as the initial positions (reference :171)
+    HIP_TRY(hipMemcpyAsync(s->best.p, s->pos[s->cur].p, (size_t)s->n * s->dim * s->real_size(),
+                           hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  });
+}
+
+int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqueued,
+                            char* errbuf, size_t errlen) {
+  if (!s || !s->began) return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (enqueued) *enqueued = 0;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    int done = 0;
+    while (done < max_iters && s->iters_enqueued < s->n_iter && !s->host_seen_stop) {
+      const int iter = s->iters_enqueued;
+      const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_for_k(s->k_host);
+      const SlabGeom g = slab_geom(s->n, stages);
+      for (int slot = 0; slot < g.n_stages; ++slot) {
+        const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
+        TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[s->cur].p, s->pos[s->cur ^ 1].p,
+                        s->state.p, rg, iter + 1, s->k_host);
+        s->cur ^= 1;
+      }
+      s->iters_enqueued = iter + 1;
+      s->k_host *= (1.0 - s->cooling);  // reference :289
+      ++done;
+      if ((iter + 1) % s->check_freq == 0 || iter == s->n_iter - 1) {  // reference :294
+        {
+          ProfScope prof(s, &s->prof_check);
+          TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[s->cur].p, s->state.p);
+          launch_controller(s, s->pos[s->cur].p, iter + 1, s->k_host);
+        }
+        hipEvent_t e = take_event(s);
+        HIP_TRY(hipEventRecord(e, s->stream));
+        s->pending.push_back(e);
+        poll_checks(s, 3);
+      }
+    }
+    if (enqueued) *enqueued = done;
+  });
+}
+
+int topolow_session_sync(topolow_session* s, int32_t* iterations_run, int32_t* stopped,
+                         double* last_mae, char* errbuf, size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    poll_checks(s, 0);
+    RunState st;
+    HIP_TRY(hipMemcpy(&st, s->state.p, sizeof st, hipMemcpyDeviceToHost));
+    if (st.stopped) s->host_seen_stop = true;
+    if (iterations_run) *iterations_run = st.stopped ? st.iter_base : s->iters_enqueued;
+    if (stopped) *stopped = st.stopped;
+    if (last_mae) *last_mae = st.last_mae;
+  });
+}
+
+int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* converged,
+                           int32_t* iterations, double* final_mae, double* final_k,
+                           char* errbuf, size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  int rc_nonfinite = TOPOLOW_OK;
+  const int rc = guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    poll_checks(s, 0);
+    RunState st;
+    HIP_TRY(hipMemcpy(&st, s->state.p, sizeof st, hipMemcpyDeviceToHost));
+    // Reference :359-361 -- positions are inspected after every 10th iteration (after that
+    // iteration's convergence check, which may already have stopped the run).
+    const int ran = st.stopped ? st.iter_base : s->iters_enqueued;
+    if (st.first_nonfinite != 0x7fffffff) {
+      const int t = ((st.first_nonfinite + 9) / 10) * 10;
+      if (t <= ran && !(st.stopped && t == ran)) {
+        set_err(errbuf, errlen,
+                "Numerical instability at iteration %d. Reduce k0 or c_repulsion.", t);
+        rc_nonfinite = TOPOLOW_ERR_NONFINITE;
+        return;
+      }
+    }
+    if (positions_out) download_positions(s, s->best.p, positions_out);
+    if (converged) *converged = st.converged;
+    if (iterations) *iterations = st.ctl.best_iter;
+    if (final_mae) *final_mae = st.ctl.best_mae;
+    if (final_k) *final_k = st.ctl.best_k;
+  });
+  return rc != TOPOLOW_OK ? rc : rc_nonfinite;
+}
+
+int topolow_session_set_profiling(topolow_session* s, int32_t enable) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  s->profiling = enable != 0;
+  return TOPOLOW_OK;
+}
+
+int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage_launches,
+                            double* check_ms, int64_t* checks, char* errbuf, size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double* ms, int64_t* cnt) {
+      double total = 0.0;
+      for (auto& pr : v) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) total += t;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+      }
+      if (ms) *ms = total;
+      if (cnt) *cnt = (int64_t)v.size();
+      v.clear();
+    };
+    drain(s->prof_stage, stage_ms, stage_launches);
+    drain(s->prof_check, check_ms, checks);
+  });
+}
+
+void* topolow_session_stream(topolow_session* s) { return s ? (void*)s->stream : nullptr; }
+
+int64_t topolow_session_stage_launches(const topolow_session* s) {
+  return s ? s->stage_launches : 0;
+}
+
+int64_t topolow_session_bytes_per_iteration(const topolow_session* s) {
+  if (!s) return 0;
+  return 4ll * s->rows() * s->n + 8ll * s->n * s->dim + 4ll * s->n;
+}
+
+int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_out,
+                          int32_t iter, int32_t stage, int32_t n_stages, double k,
+                          char* errbuf, size_t errlen) {
+  if (!s || !d_pos_in || !d_pos_out) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    const SlabGeom g = slab_geom(s->n, n_stages);
+    if (stage < 0 || stage >= g.n_stages)
+      throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "stage index out of range"};
+    const SlabRanges rg = slab_ranges(g, s->seed, iter, stage);
+    TL_DISPATCH_DIM(s->dim, launch_stage, s, d_pos_in, d_pos_out, (RunState*)nullptr, rg,
+                    iter + 1, k);
+  });
+}
+
+int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* sum,
+                               int64_t* count, char* errbuf, size_t errlen) {
+  if (!s || !d_pos || !s->part_sum.p) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    TL_DISPATCH_DIM(s->dim, launch_edge_error, s, d_pos, (const RunState*)nullptr);
+    std::vector<double> ps(s->n_parts);
+    std::vector<unsigned long long> pc(s->n_parts);
+    HIP_TRY(hipMemcpyAsync(ps.data(), s->part_sum.p, s->n_parts * 8, hipMemcpyDeviceToHost,
+                           s->stream));
+    HIP_TRY(hipMemcpyAsync(pc.data(), s->part_cnt.p, s->n_parts * 8, hipMemcpyDeviceToHost,
+                           s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    double ts = 0.0;
+    unsigned long long tc = 0;
+    for (int p = 0; p < s->n_parts; ++p) { ts += ps[p]; tc += pc[p]; }
+    if (sum) *sum = ts;
+    if (count) *count = (int64_t)tc;
+  });
+}
+
+// ---- post metric -----------------------------------------------------------------------
+int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
+                          double* est_distances, int32_t device, char* errbuf, size_t errlen) {
+  if (!positions || !est_distances || n < 1 || ndim < 1) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    select_device(device);
+    std::vector<double> rowmajor((size_t)n * ndim);
+    for (int i = 0; i < n; ++i)
+      for (int d = 0; d < ndim; ++d) rowmajor[(size_t)i * ndim + d] = positions[i + (size_t)d * n];
+    DevBuf<double> dp, dout;
+    dp.alloc(rowmajor.size());
+    dout.alloc((size_t)n * n);
+    HIP_TRY(hipMemcpy(dp.p, rowmajor.data(), rowmajor.size() * 8, hipMemcpyHostToDevice));
+    dim3 grid((n + kThreads - 1) / kThreads, n);
+    hipLaunchKernelGGL(pdist_kernel, grid, dim3(kThreads), 0, 0, dp.p, n, ndim, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(est_distances, dout.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+  });
+}
+
+// ---- the .Call payload -------------------------------------------------------------------
+int topolow_optimize_layout_exact(
+    const double* initial_positions, int32_t n, int32_t ndim,
+    const double* dissimilarity_matrix, const int32_t* threshold_matrix,
+    const int32_t* degrees, const int32_t* edge_i, const int32_t* edge_j,
+    const double* edge_dist, const int32_t* edge_thresh, int64_t n_edges, int32_t n_iter,
+    double k0, double cooling_rate, double c_repulsion, double relative_epsilon,
+    int32_t convergence_window, int32_t convergence_check_freq, int32_t verbose,
+    const topolow_options* opt_in, double* positions_out, int32_t* converged,
+    int32_t* iterations, double* final_mae, double* final_k, topolow_run_stats* stats,
+    char* errbuf, size_t errlen) {
+  if (n < 2) {  // reference :131
+    set_err(errbuf, errlen, "Need at least 2 points for embedding");
+    return TOPOLOW_ERR_TOO_FEW_POINTS;
+  }
+  if (!initial_positions || !dissimilarity_matrix || !threshold_matrix || !degrees ||
+      !positions_out || !converged || !iterations || !final_mae || !final_k ||
+      (n_edges > 0 && (!edge_i || !edge_j || !edge_dist || !edge_thresh)) || n_edges < 0) {
+    set_err(errbuf, errlen, "null argument");
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  }
+  topolow_options opt;
+  if (opt_in) opt = *opt_in; else topolow_default_options(&opt);
+  const double t_start = now_s();
+
+  int schedule = opt.schedule;
+  const int gs_max_n = opt.gs_max_n > 0 ? opt.gs_max_n : kDefaultGsMaxN;
+  if (schedule == TOPOLOW_SCHEDULE_AUTO)
+    schedule = n <= gs_max_n ? TOPOLOW_SCHEDULE_GS : TOPOLOW_SCHEDULE_SLAB;
+
+  if (schedule == TOPOLOW_SCHEDULE_GS) {
+    int precision = opt.precision == TOPOLOW_PRECISION_AUTO ? TOPOLOW_PRECISION_F64 : opt.precision;
+    GsProblem pb;
+    pb.initial_positions = initial_positions; pb.n = n; pb.dim = ndim;
+    pb.D = dissimilarity_matrix; pb.T = threshold_matrix; pb.degrees = degrees;
+    pb.edge_i = edge_i; pb.edge_j = edge_j; pb.edge_dist = edge_dist; pb.edge_thresh = edge_thresh;
+    pb.n_edges = n_edges; pb.n_iter = n_iter; pb.k0 = k0; pb.cooling = cooling_rate;
+    pb.c_rep = c_repulsion; pb.eps = relative_epsilon; pb.window = convergence_window;
+    pb.check_freq = convergence_check_freq; pb.seed = opt.seed;
+    GsResult res;
+    res.positions = positions_out;
+    int rc_inner = TOPOLOW_OK;
+    double dev_s = 0.0;
+    const int rc = guarded(errbuf, errlen, [&] {
+      select_device(opt.device);
+      rc_inner = gs_run_batch(&pb, &res, 1, precision, &dev_s, errbuf, errlen);
+    });
+    if (rc != TOPOLOW_OK) return rc;
+    if (rc_inner != TOPOLOW_OK) return rc_inner;
+    *converged = res.converged; *iterations = res.iterations; *final_mae = res.final_mae;
+    *final_k = res.final_k;
+    if (stats) {
+      std::memset(stats, 0, sizeof *stats);
+      stats->schedule_used = TOPOLOW_SCHEDULE_GS;
+      stats->precision_used = precision;
+      stats->iterations_run = res.iters_run;
+      stats->n_checks = res.n_checks;
+      stats->device_seconds = dev_s;
+      stats->total_seconds = now_s() - t_start;
+    }
+    if (verbose) std::printf("topolow_relax[gs]: n=%d iters_run=%d best_iter=%d mae=%g\n", n,
+                             res.iters_run, res.iterations, res.final_mae);
+    return TOPOLOW_OK;
+  }
+
+  // ---- slab schedule ----
+  const int precision =
+      opt.precision == TOPOLOW_PRECISION_AUTO ? TOPOLOW_PRECISION_F32 : opt.precision;
+  topolow_session* s = nullptr;
+  int rc = topolow_session_create(&s, n, ndim, 0, n, precision, opt.device, errbuf, errlen);
+  if (rc != TOPOLOW_OK) return rc;
+  double t_dev0 = 0.0, t_dev1 = 0.0;
+  int iters_run = 0, stopped = 0;
+  do {
+    rc = topolow_session_load_dense(s, dissimilarity_matrix, threshold_matrix, degrees, errbuf, errlen);
+    if (rc) break;
+    rc = topolow_session_set_edges(s, edge_i, edge_j, edge_dist, edge_thresh, n_edges, errbuf, errlen);
+    if (rc) break;
+    rc = topolow_session_set_positions(s, initial_positions, errbuf, errlen);
+    if (rc) break;
+    rc = topolow_session_begin(s, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon,
+                               convergence_window, convergence_check_freq, opt.seed,
+                               opt.slab_stages, errbuf, errlen);
+    if (rc) break;
+    t_dev0 = now_s();
+    for (;;) {
+      int enq = 0;
+      rc = topolow_session_enqueue(s, 64, &enq, errbuf, errlen);
+      if (rc || enq == 0) break;
+    }
+    if (rc) break;
+    double last = 0.0;
+    rc = topolow_session_sync(s, &iters_run, &stopped, &last, errbuf, errlen);
+    if (rc) break;
+    t_dev1 = now_s();
+    rc = topolow_session_finish(s, positions_out, converged, iterations, final_mae, final_k,
+                                errbuf, errlen);
+  } while (0);
+  if (rc == TOPOLOW_OK && stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->schedule_used = TOPOLOW_SCHEDULE_SLAB;
+    stats->precision_used = precision;
+    stats->iterations_run = iters_run;
+    stats->n_checks = s->mailbox->n_checks;
+    stats->device_seconds = t_dev1 - t_dev0;
+    stats->stage_launches = s->stage_launches;
+  }
+  if (rc == TOPOLOW_OK && verbose)
+    std::printf("topolow_relax[slab]: n=%d iters_run=%d best_iter=%d mae=%g\n", n, iters_run,
+                *iterations, *final_mae);
+  topolow_session_destroy(s);
+  if (rc == TOPOLOW_OK && stats) stats->total_seconds = now_s() - t_start;
+  return rc;
+}
+
+}  // extern "C"
