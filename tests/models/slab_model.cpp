@@ -31,7 +31,7 @@ void stage(const real* pin, real* pout, int n, int dim, const double* D, const i
     const real inv_rep = (real)1 / gi;
     for (int rg = 0; rg < n_ranges; ++rg) {
       for (int c = ranges[2 * rg]; c < ranges[2 * rg + 1]; ++c) {
-        if (c == i) continue;
+        if (c == i || c >= n) continue;  // ranges live in the padded column space [0, roundup4(n))
         real delta[16];
         real s = 0;
         for (int d = 0; d < dim; ++d) {
