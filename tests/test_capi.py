@@ -47,7 +47,7 @@ def test_target_encoding_roundtrip():
                 assert np.isfinite(v)   # huge finite targets stay measured
     for bad in (np.inf, -np.inf, np.nan):
         v, c = _native.decode_target(_native.encode_target(bad, 1))
-        assert v == np.inf and c == 0   # not finite -> unmeasured (reference :221)
+        assert v == np.inf and c == -1  # not finite -> unmeasured = (+Inf, "<"): never a spring
 
 
 @pytest.mark.parametrize("n,stages", [(10000, 4), (10001, 16), (257, 8), (50000, 64), (33, 4), (7, 16)])

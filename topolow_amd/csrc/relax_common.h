@@ -17,12 +17,17 @@ namespace topolow {
 // ---------------------------------------------------------------------------------------
 // fp32 target encoding.  One 4-byte word per ORDERED pair (row i, column c):
 //   value  = fp32(target) rounded to a multiple of 4 ulp (relative error < 3e-7)
-//   bits[1:0] = threshold code: 0 exact, 1 ">", 2 "<", 3 skip (diagonal, padding)
-//   +Inf (code 0) = unmeasured pair -> repulsion (reference src/optimization.cpp:221,269-281)
+//   bits[1:0] = threshold code: 0 exact, 1 ">", 2 "<"
+//   unmeasured pair = (+Inf, "<"): "spring if r > +Inf" never holds, so the pair always takes
+//   the repulsion branch (reference src/optimization.cpp:221,269-281) without a separate test.
+//   The diagonal and the padding columns [n, ld) also carry the unmeasured word: a point
+//   paired with itself has delta = 0 (contributes exactly 0), and padding columns are given
+//   a phantom position so far away that the repulsion coefficient underflows to exactly 0.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kCodeMask = 3u;
-constexpr uint32_t kSkipWord = 3u;           // 0.0f | skip
-constexpr uint32_t kInfWord = 0x7f800000u;   // +Inf | exact  == unmeasured
+constexpr uint32_t kInfWord = 0x7f800002u;   // +Inf | "<"  == unmeasured
+constexpr float kFarF32 = 1.0e18f;           // phantom coordinate of padding columns (f32)
+constexpr double kFarF64 = 1.0e150;          // ... (f64)
 
 TL_HD inline uint32_t f32_bits(float f) {
   union { float f; uint32_t u; } v; v.f = f; return v.u;
@@ -47,7 +52,7 @@ TL_HD inline uint32_t encode_target(double t, int code) {
 
 TL_HD inline double decode_target(uint32_t w, int* code) {
   const uint32_t c = w & kCodeMask;
-  if (code) *code = c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? -1 : 3));
+  if (code) *code = c == 0 ? 0 : (c == 1 ? 1 : -1);
   return (double)bits_f32(w & ~kCodeMask);
 }
 

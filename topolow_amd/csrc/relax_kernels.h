@@ -16,23 +16,37 @@
 
 namespace topolow {
 
-constexpr int kThreads = 256;       // 4 waves
+constexpr int kThreads = 256;       // block size of the auxiliary kernels
 constexpr int kWaves = kThreads / 64;
-constexpr int kRowsPerWave = 4;
-constexpr int kRowsPerWG = kWaves * kRowsPerWave;  // 16
-// slab columns staged in LDS at a time (multiple of 256); LDS use stays <= 40 KiB
-template <int DIM, typename real> struct ChunkOf {
-  static constexpr int value = (sizeof(real) * DIM * 1024 <= 40960) ? 1024 : ((sizeof(real) * DIM * 512 <= 40960) ? 512 : 256);
+
+// Launch geometry of the slab stage kernel.
+//   THREADS : workgroup size (waves share one LDS image of the slab's column points)
+//   RPW     : rows (points being moved) per wave; their coordinates sit in SGPRs
+//   CHUNK   : slab columns staged in LDS at a time (multiple of 256)
+//   UPFRONT : 1 = issue a whole chunk's target loads before the LDS staging, 0 = per group
+//   ABLATE  : tuning builds only -- 1 = skip the pair arithmetic (memory floor), 2 = skip the
+//             target loads (arithmetic floor); results are wrong on purpose
+template <int THREADS_, int RPW_, int CHUNK_, int UPFRONT_ = 0, int ABLATE_ = 0>
+struct StageCfg {
+  static constexpr int UPFRONT = UPFRONT_;
+  static constexpr int ABLATE = ABLATE_;
+  static constexpr int THREADS = THREADS_;
+  static constexpr int WAVES = THREADS_ / 64;
+  static constexpr int RPW = RPW_;
+  static constexpr int ROWS = WAVES * RPW_;
+  static constexpr int CHUNK = CHUNK_;
 };
 
 template <typename real> struct Math;
 template <> struct Math<float> {
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static constexpr float far() { return kFarF32; }
 };
 template <> struct Math<double> {
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static constexpr double far() { return kFarF64; }
 };
 
 // Marks a wave-uniform value so the compiler keeps it in scalar registers.
@@ -53,10 +67,13 @@ __device__ __forceinline__ real wave_sum(real v) {
   return v;
 }
 
-template <int DIM, typename real>
+// One ordered pair (row i, column c): accumulate i's half of the pair update.
+//   ks = 2k / (4 g_i + k), cg = (c_rep / 2) / g_i   (row constants, scalar registers)
+//   THR = false: the row holds no ">" / "<" targets (flag computed when the matrix is encoded),
+//   so a pair springs exactly when it is measured (target < +Inf).
+template <int DIM, typename real, bool THR>
 __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&pi)[DIM],
-                                           uint32_t w, real k2, real chalf, real inv_ns,
-                                           real inv_g, real (&acc)[DIM]) {
+                                           uint32_t w, real ks, real cg, real (&acc)[DIM]) {
   real dx[DIM];
   real s = 0;
 #pragma unroll
@@ -65,17 +82,20 @@ __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&p
     s = fma(dx[d], dx[d], s);
   }
   const real r = Math<real>::sqrt(s);
-  const real rs = r + (real)0.01;
-  const uint32_t code = w & kCodeMask;
+  const real inv = Math<real>::rcp(r + (real)0.01);
   const real t = (real)bits_f32(w & ~kCodeMask);
-  // branch-free classification (bitwise ops on purpose: no short-circuit control flow)
-  const bool measured = (w & 0x7ffffffcu) != kInfWord;
-  const bool spring = measured & ((code == 0u) | ((code == 1u) & (r < t)) | ((code == 2u) & (r > t)));
-  const real inv = Math<real>::rcp(rs);
-  const real fs = k2 * (t - r) * inv * inv_ns;
-  const real fr = chalf * inv * inv * inv * inv_g;
-  real coef = spring ? fs : fr;
-  coef = (code == 3u) ? (real)0 : coef;
+  bool spring;
+  if constexpr (THR) {
+    // branch-free classification (bitwise ops on purpose: no short-circuit control flow);
+    // unmeasured pairs are (+Inf, "<") and therefore never spring
+    const uint32_t code = w & kCodeMask;
+    spring = (code == 0u) | ((code == 1u) & (r < t)) | ((code == 2u) & (r > t));
+  } else {
+    spring = t < (real)INFINITY;
+  }
+  const real fs = (t - r) * inv * ks;
+  const real fr = inv * inv * inv * cg;
+  const real coef = spring ? fs : fr;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc[d] = fma(dx[d], coef, acc[d]);
 }
@@ -86,43 +106,45 @@ __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&p
 //   pos_out : n x DIM row-major; rows [row_begin,row_end) are written
 //   st      : run state (nullable): launch is a no-op once st->stopped is set; non-finite
 //             results are reported through st->first_nonfinite
-template <int DIM, typename real>
-__global__ __launch_bounds__(kThreads) void slab_stage_kernel(
+template <int DIM, typename real, typename CFG>
+__global__ __launch_bounds__(CFG::THREADS) void slab_stage_kernel(
     const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
     const real* __restrict__ pos_in, real* __restrict__ pos_out,
-    const float* __restrict__ gplus, RunState* st, SlabRanges rg, int iter1, double k,
-    double c_rep) {
+    const float* __restrict__ gplus, const unsigned char* __restrict__ rowflags, RunState* st,
+    SlabRanges rg, int iter1, double k, double c_rep) {
   if (st != nullptr && st->stopped) return;
 
-  constexpr int kChunk = ChunkOf<DIM, real>::value;
-  __shared__ real lds_pos[DIM * kChunk];
+  constexpr int kChunk = CFG::CHUNK;
+  constexpr int RPW = CFG::RPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char slab_smem[];
+  real* lds_pos = reinterpret_cast<real*>(slab_smem);  // [DIM][kChunk]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = row_begin + blockIdx.x * kRowsPerWG + wave * kRowsPerWave;
+  const int row0 = row_begin + blockIdx.x * CFG::ROWS + wave * RPW;
 
-  const real k2 = (real)(2.0 * k);
-  const real chalf = (real)(0.5 * c_rep);
-
-  real pi[kRowsPerWave][DIM];
-  real acc[kRowsPerWave][DIM];
-  real inv_ns[kRowsPerWave], inv_g[kRowsPerWave];
-  const uint32_t* rowp[kRowsPerWave];
+  real pi[RPW][DIM];
+  real acc[RPW][DIM];
+  real ks[RPW], cg[RPW];
+  const uint32_t* rowp[RPW];
+  int thr_any = 0;  // wave-uniform: do any of this wave's rows hold threshold targets?
 #pragma unroll
-  for (int r = 0; r < kRowsPerWave; ++r) {
+  for (int r = 0; r < RPW; ++r) {
     const int row = row0 + r;
     const int rr = row < row_end ? row : row_end - 1;  // clamp: result discarded below
+    thr_any |= rowflags[rr - row_begin];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
       pi[r][d] = uniform(pos_in[(size_t)rr * DIM + d]);  // wave-uniform: lives in SGPRs
       acc[r][d] = 0;
     }
     const real g = (real)gplus[rr];
-    inv_ns[r] = uniform((real)1 / ((real)4 * g + (real)k));
-    inv_g[r] = uniform((real)1 / g);
+    ks[r] = uniform((real)(2.0 * k) / ((real)4 * g + (real)k));
+    cg[r] = uniform((real)(0.5 * c_rep) / g);
     rowp[r] = denc + (size_t)(rr - row_begin) * ld;
   }
+  const bool thr = __builtin_amdgcn_readfirstlane(thr_any) != 0;
 
 #pragma unroll 1
   for (int part = 0; part < 2; ++part) {
@@ -131,40 +153,111 @@ __global__ __launch_bounds__(kThreads) void slab_stage_kernel(
 #pragma unroll 1
     for (int cb = rb; cb < re; cb += kChunk) {
       const int cw = min(kChunk, re - cb);  // multiple of 4
+      if constexpr (CFG::UPFRONT) {
+      // Issue this chunk's target words first (kChunk/256 column groups x RPW rows of 16 B per
+      // lane stay in flight), so their HBM latency overlaps the LDS staging below.
+      constexpr int kGroups = kChunk / 256;
+      uint4 w4[kGroups][RPW];
+#pragma unroll
+      for (int t = 0; t < kGroups; ++t) {
+        const int c4 = lane * 4 + t * 256;
+        if (c4 < cw) {
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+            w4[t][r] = *reinterpret_cast<const uint4*>(rowp[r] + cb + c4);
+        }
+      }
       __syncthreads();  // previous chunk fully consumed
-      // stage column points [cb, cb+cw) into LDS, structure-of-arrays
-      for (int c = tid; c < cw; c += kThreads) {
+      // stage column points [cb, cb+cw) into LDS, structure-of-arrays; padding columns get a
+      // phantom point far away (see relax_common.h)
+      for (int c = tid; c < cw; c += CFG::THREADS) {
         const int col = cb + c;
 #pragma unroll
         for (int d = 0; d < DIM; ++d)
-          lds_pos[d * kChunk + c] = col < n ? pos_in[(size_t)col * DIM + d] : (real)0;
+          lds_pos[d * kChunk + c] =
+              col < n ? pos_in[(size_t)col * DIM + d] : (d == 0 ? Math<real>::far() : (real)0);
       }
       __syncthreads();
-#pragma unroll 1
-      for (int c4 = lane * 4; c4 < cw; c4 += 256) {
-        uint4 w4[kRowsPerWave];
 #pragma unroll
-        for (int r = 0; r < kRowsPerWave; ++r)
-          w4[r] = *reinterpret_cast<const uint4*>(rowp[r] + cb + c4);
-        real pc[4][DIM];
+      for (int t = 0; t < kGroups; ++t) {
+        const int c4 = lane * 4 + t * 256;
+        if (c4 < cw) {
+          real pc[4][DIM];
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) {
+          for (int d = 0; d < DIM; ++d) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) pc[q][d] = lds_pos[d * kChunk + c4 + q];
+            for (int q = 0; q < 4; ++q) pc[q][d] = lds_pos[d * kChunk + c4 + q];
+          }
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            if (thr) {
+              pair_accum<DIM, real, true>(pc[0], pi[r], w4[t][r].x, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[1], pi[r], w4[t][r].y, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[2], pi[r], w4[t][r].z, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[3], pi[r], w4[t][r].w, ks[r], cg[r], acc[r]);
+            } else {
+              pair_accum<DIM, real, false>(pc[0], pi[r], w4[t][r].x, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[1], pi[r], w4[t][r].y, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[2], pi[r], w4[t][r].z, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[3], pi[r], w4[t][r].w, ks[r], cg[r], acc[r]);
+            }
+          }
         }
+      }
+      } else {
+        __syncthreads();  // previous chunk fully consumed
+        for (int c = tid; c < cw; c += CFG::THREADS) {
+          const int col = cb + c;
 #pragma unroll
-        for (int r = 0; r < kRowsPerWave; ++r) {
-          pair_accum<DIM, real>(pc[0], pi[r], w4[r].x, k2, chalf, inv_ns[r], inv_g[r], acc[r]);
-          pair_accum<DIM, real>(pc[1], pi[r], w4[r].y, k2, chalf, inv_ns[r], inv_g[r], acc[r]);
-          pair_accum<DIM, real>(pc[2], pi[r], w4[r].z, k2, chalf, inv_ns[r], inv_g[r], acc[r]);
-          pair_accum<DIM, real>(pc[3], pi[r], w4[r].w, k2, chalf, inv_ns[r], inv_g[r], acc[r]);
+          for (int d = 0; d < DIM; ++d)
+            lds_pos[d * kChunk + c] =
+                col < n ? pos_in[(size_t)col * DIM + d] : (d == 0 ? Math<real>::far() : (real)0);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int c4 = lane * 4; c4 < cw; c4 += 256) {
+          uint4 w4[RPW];
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            if constexpr (CFG::ABLATE == 2) {
+              w4[r] = make_uint4(0x40000000u + c4, 0x40400002u, 0x7f800002u, 0x40800001u);
+            } else {
+              w4[r] = *reinterpret_cast<const uint4*>(rowp[r] + cb + c4);
+            }
+          }
+          if constexpr (CFG::ABLATE == 1) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+              acc[r][0] += __builtin_bit_cast(float, w4[r].x ^ w4[r].y ^ w4[r].z ^ w4[r].w);
+            continue;
+          }
+          real pc[4][DIM];
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pc[q][d] = lds_pos[d * kChunk + c4 + q];
+          }
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            if (thr) {
+              pair_accum<DIM, real, true>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
+            } else {
+              pair_accum<DIM, real, false>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
+            }
+          }
         }
       }
     }
   }
 
 #pragma unroll
-  for (int r = 0; r < kRowsPerWave; ++r) {
+  for (int r = 0; r < RPW; ++r) {
     const int row = row0 + r;
     bool finite = true;
     real out[DIM];
@@ -282,7 +375,7 @@ __global__ __launch_bounds__(kThreads) void encode_dense_kernel(
   const int c = blockIdx.x * kThreads + threadIdx.x;
   const int i = row_begin + blockIdx.y;
   if (c >= ld || i >= row_end) return;
-  uint32_t w = kSkipWord;
+  uint32_t w = kInfWord;  // diagonal and padding: see relax_common.h
   if (c < n && c != i) {
     const int lo = i < c ? i : c, hi = i < c ? c : i;
     const size_t cell = (size_t)lo + (size_t)hi * n;
@@ -291,12 +384,28 @@ __global__ __launch_bounds__(kThreads) void encode_dense_kernel(
   out[(size_t)(i - row_begin) * ld + c] = w;
 }
 
+// rowflags[i] = 1 when encoded row i holds a ">" target or a measured "<" target.
+__global__ __launch_bounds__(kThreads) void row_flags_kernel(const uint32_t* __restrict__ enc,
+                                                             int rows, int ld,
+                                                             unsigned char* __restrict__ flags) {
+  const int i = blockIdx.x;
+  if (i >= rows) return;
+  int any = 0;
+  for (int c = threadIdx.x; c < ld; c += kThreads) {
+    const uint32_t w = enc[(size_t)i * ld + c];
+    const uint32_t code = w & kCodeMask;
+    any |= (code == 1u) | ((code == 2u) & (w != kInfWord));
+  }
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) flags[i] = any ? 1 : 0;
+}
+
 __global__ __launch_bounds__(kThreads) void fill_unmeasured_kernel(
     int n, int row_begin, int row_end, int ld, uint32_t* __restrict__ out) {
   const int c = blockIdx.x * kThreads + threadIdx.x;
   const int i = row_begin + blockIdx.y;
   if (c >= ld || i >= row_end) return;
-  out[(size_t)(i - row_begin) * ld + c] = (c < n && c != i) ? kInfWord : kSkipWord;
+  out[(size_t)(i - row_begin) * ld + c] = kInfWord;
 }
 
 __global__ __launch_bounds__(kThreads) void scatter_edges_kernel(

@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <deque>
 #include <string>
 #include <vector>
@@ -105,6 +106,7 @@ struct topolow_session {
 
   DevBuf<uint32_t> enc;
   DevBuf<float> gplus;
+  DevBuf<unsigned char> rowflags;
   DevBuf<unsigned char> pos[2];
   DevBuf<unsigned char> best;
   DevBuf<int> ei, ej;
@@ -183,20 +185,61 @@ struct ProfScope {
   }
 };
 
+// Stage-kernel geometry variants (TOPOLOW_SLAB_VARIANT selects one at run time for tuning).
+using CfgA = StageCfg<256, 4, 1024>;   // 16 rows / WG
+using CfgB = StageCfg<512, 2, 1024>;   // 16 rows / WG, twice the waves
+using CfgC = StageCfg<512, 2, 2560>;   // whole 10k/4 slab in one LDS image
+using CfgD = StageCfg<256, 2, 1024>;   // 8 rows / WG
+using CfgE = StageCfg<512, 4, 1024>;   // 32 rows / WG
+using CfgF = StageCfg<256, 2, 1024, 1>;      // D + upfront loads
+using CfgG = StageCfg<256, 2, 1024, 0, 1>;   // D, memory only (tuning)
+using CfgH = StageCfg<256, 2, 1024, 0, 2>;   // D, arithmetic only (tuning)
+
+int slab_variant() {
+  static int v = [] {
+    const char* e = getenv("TOPOLOW_SLAB_VARIANT");
+    return e ? atoi(e) : 3;
+  }();
+  return v;
+}
+
+template <int DIM, typename real, typename CFG>
+void launch_stage_cfg(topolow_session* s, const void* pin, void* pout, RunState* st,
+                      SlabRanges rg, int iter1, double k) {
+  const int blocks = (s->rows() + CFG::ROWS - 1) / CFG::ROWS;
+  const size_t lds = sizeof(real) * DIM * CFG::CHUNK;
+  auto kern = &slab_stage_kernel<DIM, real, CFG>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), lds, s->stream, s->enc.p, s->ld,
+                     s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
+                     s->rowflags.p, st, rg, iter1, k, s->c_rep);
+}
+
 template <int DIM>
 void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st, SlabRanges rg,
                   int iter1, double k) {
-  const int blocks = (s->rows() + kRowsPerWG - 1) / kRowsPerWG;
-  if (blocks <= 0) return;
+  if (s->rows() <= 0) return;
   ProfScope prof(s, &s->prof_stage);
   if (s->precision == TOPOLOW_PRECISION_F64) {
-    hipLaunchKernelGGL((slab_stage_kernel<DIM, double>), dim3(blocks), dim3(kThreads), 0,
-                       s->stream, s->enc.p, s->ld, s->row_begin, s->row_end, s->n,
-                       (const double*)pin, (double*)pout, s->gplus.p, st, rg, iter1, k, s->c_rep);
+    launch_stage_cfg<DIM, double, StageCfg<256, 2, 512>>(s, pin, pout, st, rg, iter1, k);
   } else {
-    hipLaunchKernelGGL((slab_stage_kernel<DIM, float>), dim3(blocks), dim3(kThreads), 0,
-                       s->stream, s->enc.p, s->ld, s->row_begin, s->row_end, s->n,
-                       (const float*)pin, (float*)pout, s->gplus.p, st, rg, iter1, k, s->c_rep);
+    switch (slab_variant()) {
+      case 0: launch_stage_cfg<DIM, float, CfgA>(s, pin, pout, st, rg, iter1, k); break;
+      case 2: launch_stage_cfg<DIM, float, CfgC>(s, pin, pout, st, rg, iter1, k); break;
+      case 3: launch_stage_cfg<DIM, float, CfgD>(s, pin, pout, st, rg, iter1, k); break;
+      case 4: launch_stage_cfg<DIM, float, CfgE>(s, pin, pout, st, rg, iter1, k); break;
+      case 5: launch_stage_cfg<DIM, float, CfgF>(s, pin, pout, st, rg, iter1, k); break;
+      case 6: launch_stage_cfg<DIM, float, CfgG>(s, pin, pout, st, rg, iter1, k); break;
+      case 7: launch_stage_cfg<DIM, float, CfgH>(s, pin, pout, st, rg, iter1, k); break;
+      default: launch_stage_cfg<DIM, float, CfgB>(s, pin, pout, st, rg, iter1, k); break;
+    }
   }
   HIP_TRY(hipGetLastError());
   s->stage_launches += 1;
@@ -266,6 +309,14 @@ void download_positions(topolow_session* s, const void* src, double* host_colmaj
       for (int d = 0; d < s->dim; ++d)
         host_colmajor[i + (size_t)d * s->n] = (double)tmp[(size_t)i * s->dim + d];
   }
+}
+
+void compute_row_flags(topolow_session* s) {
+  s->rowflags.alloc(s->rows());
+  hipLaunchKernelGGL(row_flags_kernel, dim3(s->rows()), dim3(kThreads), 0, s->stream, s->enc.p,
+                     s->rows(), s->ld, s->rowflags.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
 }
 
 void upload_degrees(topolow_session* s, const int32_t* degrees) {
@@ -454,6 +505,7 @@ int topolow_session_load_dense(topolow_session* s, const double* D, const int32_
                        s->row_begin, s->row_end, s->ld, s->enc.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
+    compute_row_flags(s);
     upload_degrees(s, degrees);
   });
 }
@@ -487,6 +539,7 @@ int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const in
       HIP_TRY(hipStreamSynchronize(s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
+    compute_row_flags(s);
     upload_degrees(s, degrees);
   });
 }
