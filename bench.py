@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--stages", type=int, default=0, help="fixed slab stages (0 = adaptive)")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="multi-GPU mode: independent config-3 embeddings per GPU (weak scaling, "
+                         "default) or ONE row-sharded config-4 embedding (strong scaling)")
     return ap.parse_args()
 
 
@@ -171,7 +174,7 @@ def run_single(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.mode == "sharded":
         from topolow_amd import sharded
         sharded.bench_main(args)
     else:

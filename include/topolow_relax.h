@@ -124,6 +124,13 @@ int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const in
                              const double* edge_dist, const int32_t* edge_thresh,
                              int64_t n_edges, const int32_t* degrees, char* errbuf,
                              size_t errlen);
+/* Device-side fill: the caller writes the session's encoded block itself (a device buffer of
+ * (row_end-row_begin) x ld uint32 words, word = topolow_encode_target(); diagonal, padding
+ * and unmeasured cells = topolow_encode_target(+Inf, 0)), then commits it with the degrees. */
+void* topolow_session_encoded_ptr(topolow_session* s);
+int32_t topolow_session_encoded_ld(const topolow_session* s);
+int topolow_session_commit_encoded(topolow_session* s, const int32_t* degrees, char* errbuf,
+                                   size_t errlen);
 /* Edge list used by the convergence MAE (host pointers).  For a row-sharded session pass
  * only the edges this rank should reduce (e.g. those with edge_i in its row block). */
 int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const int32_t* edge_j,
@@ -158,6 +165,10 @@ int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* c
 int topolow_session_set_profiling(topolow_session* s, int32_t enable);
 int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage_launches,
                             double* check_ms, int64_t* checks, char* errbuf, size_t errlen);
+/* Makes the session launch on the caller's stream (a hipStream_t, e.g. the stream
+ * torch.distributed collectives are ordered on) instead of its own; the caller keeps
+ * ownership.  Pass NULL to return to the session's private stream. */
+int topolow_session_set_stream(topolow_session* s, void* hip_stream);
 /* HIP stream (hipStream_t) the session launches on, for event timing by the caller. */
 void* topolow_session_stream(topolow_session* s);
 /* Number of slab-stage kernel launches so far, and the algorithmic bytes one iteration

@@ -1,0 +1,142 @@
+"""Row-sharded driver (topolow_amd/sharded.py) on CPU: two gloo ranks must reproduce the
+single-rank run exactly.  The HIP stage is replaced by the CPU slab model (tests only), so this
+covers the partitioning, the in-place all-gather of position slices, the all-reduce of the
+MAE scalars and the replicated controller -- everything except the kernels themselves."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import topolow_oracle as orc
+from tests.models import slab_model
+from topolow_amd import _native, core, sharded, synthetic
+
+
+class ModelBackend:
+    """CPU stand-in for sharded.HipBackend: same interface, slab model + oracle MAE."""
+
+    def __init__(self, call, row_begin, row_end, edge_slice):
+        self.call = call
+        self.n, self.ndim = call.initial_positions.shape
+        self.rb, self.re = row_begin, row_end
+        self.edges = edge_slice
+        self.seed = 0
+
+    def new_positions(self, rows_total):
+        return torch.zeros((rows_total, self.ndim), dtype=torch.float64)
+
+    def to_device(self, pos_np, rows_total):
+        t = self.new_positions(rows_total)
+        t[: self.n] = torch.from_numpy(np.asarray(pos_np, dtype=np.float64))
+        return t
+
+    def to_host(self, t):
+        return t[: self.n].numpy().copy()
+
+    def begin(self, n_iter, k0, cool, c_rep, seed):
+        self.seed, self.c_rep = seed, c_rep
+
+    def stage(self, pos_in, pos_out, it, slot, stages, k):
+        c = self.call
+        rg = _native.slab_plan(self.n, stages, self.seed, it)[slot].reshape(2, 2)
+        rg = [r for r in rg if r[1] > r[0]]
+        new = slab_model.stage(pos_in[: self.n].numpy(), c.dissimilarity_matrix, c.threshold_matrix,
+                               c.degrees, rg, k, self.c_rep, "f64")
+        pos_out[self.rb:self.re] = torch.from_numpy(new[self.rb:self.re])
+
+    def edge_error(self, pos):
+        c = self.call
+        sl = self.edges
+        return orc.edge_error(pos[: self.n].numpy(), c.edge_i[sl], c.edge_j[sl], c.edge_dist[sl],
+                              c.edge_thresh[sl])
+
+    def all_finite(self, pos):
+        return bool(torch.isfinite(pos[: self.n]).all())
+
+    def clone(self, pos):
+        return pos.clone()
+
+    def synchronize(self):
+        pass
+
+
+def _problem():
+    prob = synthetic.make_problem(151, latent_dim=3, missing=0.6, seed=5)
+    init = synthetic.initial_positions(prob.dissimilarity, 3, 5)
+    return core.prepare_layout_call(prob.dissimilarity, 3, 40, 9.0, 0.05, 0.02, 1e-4, 3, init, False, 3, True)
+
+
+def _run(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    call = _problem()
+    n = call.initial_positions.shape[0]
+    b, e, _ = sharded.row_block(n, world, rank)
+    E = call.edge_i.shape[0]
+    sl = slice(rank * E // world, (rank + 1) * E // world)
+    backend = ModelBackend(call, b, e, sl)
+    coll = sharded.Collectives(world)
+    res = sharded.relax_sharded(backend, coll, rank, world, n, call.initial_positions, call.n_iter,
+                                call.k0, call.cooling_rate, call.c_repulsion, call.relative_epsilon,
+                                call.convergence_window, call.convergence_check_freq, seed=31)
+    q.put((rank, res.positions, res.converged, res.iterations, res.final_mae, res.final_k,
+           res.iterations_run))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(outs, key=lambda o: o[0])
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_equal_one_rank():
+    one = _launch(1)[0]
+    two = _launch(2)
+    for rank_out in two:
+        assert np.array_equal(rank_out[1], one[1])          # identical positions on every rank
+        assert rank_out[2:] == pytest.approx(one[2:], rel=1e-12)
+    assert one[6] >= one[3] > 0
+
+
+def test_row_blocks_cover_everything():
+    for n, world in ((50000, 8), (10, 4), (7, 8), (151, 2)):
+        blocks = [sharded.row_block(n, world, r) for r in range(world)]
+        cover = np.zeros(n, int)
+        for b, e, per in blocks:
+            cover[b:e] += 1
+            assert e - b <= per
+        assert np.all(cover == 1)
+
+
+def test_torch_encoder_matches_c_encoder():
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.uniform(0, 40, 500), [0.0, 0.1, 1e-30, 3.3e38, np.inf, np.nan]])
+    w = sharded.encode_words_torch(torch, torch.from_numpy(vals)).numpy()
+    for v, got in zip(vals, w):
+        assert int(got) == _native.encode_target(float(v), 0)

@@ -102,6 +102,12 @@ def load() -> C.CDLL:
     lib.topolow_session_load_coo.restype = C.c_int
     lib.topolow_session_load_coo.argtypes = [vp, ip, ip, dp, ip, C.c_int64, ip, C.c_char_p,
                                              C.c_size_t]
+    lib.topolow_session_encoded_ptr.restype = vp
+    lib.topolow_session_encoded_ptr.argtypes = [vp]
+    lib.topolow_session_encoded_ld.restype = C.c_int32
+    lib.topolow_session_encoded_ld.argtypes = [vp]
+    lib.topolow_session_commit_encoded.restype = C.c_int
+    lib.topolow_session_commit_encoded.argtypes = [vp, ip, C.c_char_p, C.c_size_t]
     lib.topolow_session_set_edges.restype = C.c_int
     lib.topolow_session_set_edges.argtypes = [vp, ip, ip, dp, ip, C.c_int64, C.c_char_p, C.c_size_t]
     lib.topolow_session_set_positions.restype = C.c_int
@@ -123,6 +129,8 @@ def load() -> C.CDLL:
     lib.topolow_session_profile.restype = C.c_int
     lib.topolow_session_profile.argtypes = [vp, dp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64),
                                             C.c_char_p, C.c_size_t]
+    lib.topolow_session_set_stream.restype = C.c_int
+    lib.topolow_session_set_stream.argtypes = [vp, vp]
     lib.topolow_session_stream.restype = vp
     lib.topolow_session_stream.argtypes = [vp]
     lib.topolow_session_stage_launches.restype = C.c_int64
@@ -351,6 +359,20 @@ class Session:
                                                  int(ei.shape[0]), _ip(deg), self._err,
                                                  len(self._err)), self._err)
 
+    @property
+    def encoded_ptr(self) -> int:
+        return int(self.lib.topolow_session_encoded_ptr(self._h) or 0)
+
+    @property
+    def encoded_ld(self) -> int:
+        return int(self.lib.topolow_session_encoded_ld(self._h))
+
+    def commit_encoded(self, degrees):
+        deg = np.ascontiguousarray(degrees, dtype=np.int32)
+        assert deg.shape[0] == self.n
+        _check(self.lib.topolow_session_commit_encoded(self._h, _ip(deg), self._err,
+                                                       len(self._err)), self._err)
+
     def set_edges(self, ei, ej, ed, et):
         ei = np.ascontiguousarray(ei, dtype=np.int32)
         ej = np.ascontiguousarray(ej, dtype=np.int32)
@@ -416,6 +438,9 @@ class Session:
         _check(self.lib.topolow_session_profile(self._h, C.byref(sm), C.byref(sl), C.byref(cm),
                                                 C.byref(cl), self._err, len(self._err)), self._err)
         return float(sm.value), int(sl.value), float(cm.value), int(cl.value)
+
+    def set_stream(self, hip_stream: int):
+        self.lib.topolow_session_set_stream(self._h, C.c_void_p(hip_stream or None))
 
     @property
     def stream(self) -> int:

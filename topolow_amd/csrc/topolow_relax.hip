@@ -103,6 +103,7 @@ struct topolow_session {
   int precision = TOPOLOW_PRECISION_F32;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
 
   DevBuf<uint32_t> enc;
   DevBuf<float> gplus;
@@ -146,7 +147,7 @@ struct topolow_session {
     for (hipEvent_t e : pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (mailbox) (void)hipHostFree(mailbox);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
   }
 };
 
@@ -465,7 +466,8 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     s->ld = (n + 63) & ~63;
     s->precision = precision == TOPOLOW_PRECISION_F64 ? TOPOLOW_PRECISION_F64
                                                       : TOPOLOW_PRECISION_F32;
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
     s->enc.alloc((size_t)s->rows() * s->ld);
     const size_t pos_bytes = (size_t)n * ndim * s->real_size();
     s->pos[0].alloc(pos_bytes);
@@ -539,6 +541,20 @@ int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const in
       HIP_TRY(hipStreamSynchronize(s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
+    compute_row_flags(s);
+    upload_degrees(s, degrees);
+  });
+}
+
+void* topolow_session_encoded_ptr(topolow_session* s) { return s ? (void*)s->enc.p : nullptr; }
+int32_t topolow_session_encoded_ld(const topolow_session* s) { return s ? s->ld : 0; }
+
+int topolow_session_commit_encoded(topolow_session* s, const int32_t* degrees, char* errbuf,
+                                   size_t errlen) {
+  if (!s || !degrees) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());  // the caller filled the block on another stream
     compute_row_flags(s);
     upload_degrees(s, degrees);
   });
@@ -752,6 +768,14 @@ int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage
     drain(s->prof_stage, stage_ms, stage_launches);
     drain(s->prof_check, check_ms, checks);
   });
+}
+
+int topolow_session_set_stream(topolow_session* s, void* hip_stream) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  return TOPOLOW_OK;
 }
 
 void* topolow_session_stream(topolow_session* s) { return s ? (void*)s->stream : nullptr; }
