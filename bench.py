@@ -6,9 +6,11 @@ convergence check the reference runs every `convergence_check_freq`=3 iterations
 
   N = 1 : BASELINE.json config 3 -- synthetic N=10 000, 70 % missing, ndim=5, k0=5,
           cooling=0.01, c_repulsion=0.01 -- one embedding on one GPU, targets resident in HBM.
-  N > 1 : BASELINE.json config 4 -- synthetic N=50 000, 90 % missing, ndim=3 -- ONE embedding
-          row-block sharded over the ranks (all-gather of position slices after every slab
-          stage over RCCL); total work fixed => "scaling": "strong".
+  N > 1 : default `--mode replicas`: N independent config-3 embeddings, one per GPU, no
+          data-path collective (the reference's own parallel mode) => "scaling": "weak";
+          `--mode sharded`: BASELINE.json config 4 -- synthetic N=50 000, 90 % missing, ndim=3 --
+          ONE embedding row-block sharded over the ranks (all-gather of position slices after
+          every slab stage over RCCL) => "scaling": "strong".
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (slab_stage_kernel):
 algorithmic bytes per launch = (4*rows*N + 8*N*ndim + 4*N) / stages, divided by its mean
@@ -35,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--n", type=int, default=0, help="override the number of points (testing)")
+    ap.add_argument("--points", dest="n", type=int, default=0, help="override the number of points (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--stages", type=int, default=0, help="fixed slab stages (0 = adaptive)")

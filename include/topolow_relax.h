@@ -165,10 +165,11 @@ int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* c
 int topolow_session_set_profiling(topolow_session* s, int32_t enable);
 int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage_launches,
                             double* check_ms, int64_t* checks, char* errbuf, size_t errlen);
-/* Makes the session launch on the caller's stream (a hipStream_t, e.g. the stream
- * torch.distributed collectives are ordered on) instead of its own; the caller keeps
- * ownership.  Pass NULL to return to the session's private stream. */
-int topolow_session_set_stream(topolow_session* s, void* hip_stream);
+/* external != 0: the session launches on the caller's stream `hip_stream` (a hipStream_t; NULL
+ * is the device's default stream, which is what torch uses unless told otherwise), so its
+ * kernels are ordered with the caller's copies and collectives; the caller keeps ownership.
+ * external == 0: back to the session's private non-blocking stream. */
+int topolow_session_set_stream(topolow_session* s, void* hip_stream, int32_t external);
 /* HIP stream (hipStream_t) the session launches on, for event timing by the caller. */
 void* topolow_session_stream(topolow_session* s);
 /* Number of slab-stage kernel launches so far, and the algorithmic bytes one iteration

@@ -130,7 +130,7 @@ def load() -> C.CDLL:
     lib.topolow_session_profile.argtypes = [vp, dp, C.POINTER(C.c_int64), dp, C.POINTER(C.c_int64),
                                             C.c_char_p, C.c_size_t]
     lib.topolow_session_set_stream.restype = C.c_int
-    lib.topolow_session_set_stream.argtypes = [vp, vp]
+    lib.topolow_session_set_stream.argtypes = [vp, vp, C.c_int32]
     lib.topolow_session_stream.restype = vp
     lib.topolow_session_stream.argtypes = [vp]
     lib.topolow_session_stage_launches.restype = C.c_int64
@@ -439,8 +439,10 @@ class Session:
                                                 C.byref(cl), self._err, len(self._err)), self._err)
         return float(sm.value), int(sl.value), float(cm.value), int(cl.value)
 
-    def set_stream(self, hip_stream: int):
-        self.lib.topolow_session_set_stream(self._h, C.c_void_p(hip_stream or None))
+    def set_stream(self, hip_stream, external: bool = True):
+        """hip_stream: integer hipStream_t (0/None = the device's default stream)."""
+        self.lib.topolow_session_set_stream(self._h, C.c_void_p(hip_stream or None),
+                                            int(bool(external)))
 
     @property
     def stream(self) -> int:

@@ -770,11 +770,11 @@ int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage
   });
 }
 
-int topolow_session_set_stream(topolow_session* s, void* hip_stream) {
+int topolow_session_set_stream(topolow_session* s, void* hip_stream, int32_t external) {
   if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
-  s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  s->stream = external ? (hipStream_t)hip_stream : s->own_stream;
   return TOPOLOW_OK;
 }
 
