@@ -135,7 +135,7 @@ def run_single(args):
         "config": {"workload": f"config 3: synthetic N={n}, 70% missing, ndim=5, k0=5, cooling=0.01, "
                                "c_repulsion=0.01, check every 3 iterations",
                    "n_points": n, "ndim": ndim, "schedule": "slab", "stages_per_iteration": stages_per_iter,
-                   "edges": int(call.edge_i.size)},
+                   "edges": int(call.edge_i.size), "mae_pass": "dense" if s.uses_dense_mae else "edges"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": "slab_stage_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,

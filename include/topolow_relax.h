@@ -172,6 +172,9 @@ int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage
 int topolow_session_set_stream(topolow_session* s, void* hip_stream, int32_t external);
 /* HIP stream (hipStream_t) the session launches on, for event timing by the caller. */
 void* topolow_session_stream(topolow_session* s);
+/* 1 when the convergence MAE is reduced from the encoded block (the edge list was verified to be
+ * exactly its measured cells), 0 when it gathers the caller's edge list. */
+int32_t topolow_session_uses_dense_mae(const topolow_session* s);
 /* Number of slab-stage kernel launches so far, and the algorithmic bytes one iteration
  * moves (4*rows*n + 8*n*ndim + 4*n). */
 int64_t topolow_session_stage_launches(const topolow_session* s);
@@ -182,6 +185,10 @@ int64_t topolow_session_bytes_per_iteration(const topolow_session* s);
  * caller's, e.g. torch.distributed/RCCL).  d_pos_* are device pointers to n x ndim
  * row-major positions in the session's precision.
  * ------------------------------------------------------------------------------------- */
+/* Rows a caller-owned position buffer must hold: roundup4(n).  Rows [n, roundup4(n)) are the
+ * phantom points of the padding columns and must be (1e18, 0, ..., 0) (1e150 in f64 sessions) in
+ * BOTH ping-pong buffers; stages never write them. */
+int32_t topolow_session_position_rows(const topolow_session* s);
 /* Launches stage `stage` of iteration `iter` (0-based) for the session's row block: reads
  * all n positions from d_pos_in, writes rows [row_begin,row_end) of d_pos_out. */
 int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_out,

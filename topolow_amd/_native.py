@@ -19,6 +19,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtopolow_relax.so")
 SCHEDULE_AUTO, SCHEDULE_SLAB, SCHEDULE_GS = 0, 1, 2
 PRECISION_AUTO, PRECISION_F32, PRECISION_F64 = 0, 1, 2
 
+FAR_F32 = 1.0e18   # phantom coordinate of padding points (relax_common.h)
+
 OK = 0
 ERR_TOO_FEW_POINTS, ERR_NONFINITE, ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = \
     1, 2, 3, 4, 5, 6
@@ -133,6 +135,10 @@ def load() -> C.CDLL:
     lib.topolow_session_set_stream.argtypes = [vp, vp, C.c_int32]
     lib.topolow_session_stream.restype = vp
     lib.topolow_session_stream.argtypes = [vp]
+    lib.topolow_session_position_rows.restype = C.c_int32
+    lib.topolow_session_position_rows.argtypes = [vp]
+    lib.topolow_session_uses_dense_mae.restype = C.c_int32
+    lib.topolow_session_uses_dense_mae.argtypes = [vp]
     lib.topolow_session_stage_launches.restype = C.c_int64
     lib.topolow_session_stage_launches.argtypes = [vp]
     lib.topolow_session_bytes_per_iteration.restype = C.c_int64
@@ -447,6 +453,14 @@ class Session:
     @property
     def stream(self) -> int:
         return int(self.lib.topolow_session_stream(self._h) or 0)
+
+    @property
+    def position_rows(self) -> int:
+        return int(self.lib.topolow_session_position_rows(self._h))
+
+    @property
+    def uses_dense_mae(self) -> bool:
+        return bool(self.lib.topolow_session_uses_dense_mae(self._h))
 
     @property
     def stage_launches(self) -> int:

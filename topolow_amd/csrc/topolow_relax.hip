@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <deque>
@@ -108,6 +109,7 @@ struct topolow_session {
   DevBuf<uint32_t> enc;
   DevBuf<float> gplus;
   DevBuf<unsigned char> rowflags;
+  bool any_threshold = true;   // does any row of the block hold a ">" / "<" target?
   DevBuf<unsigned char> pos[2];
   DevBuf<unsigned char> best;
   DevBuf<int> ei, ej;
@@ -115,6 +117,9 @@ struct topolow_session {
   DevBuf<int8_t> ec;
   long long n_edges = 0;
   int n_parts = 0;
+  bool dense_mae = false;   // edge list verified == measured cells of the encoded block
+  bool dense_parity = false;
+  int dense_blocks = 0;
   DevBuf<double> part_sum;
   DevBuf<unsigned long long> part_cnt;
   DevBuf<RunState> state;
@@ -140,6 +145,7 @@ struct topolow_session {
 
   size_t real_size() const { return precision == TOPOLOW_PRECISION_F64 ? 8 : 4; }
   int rows() const { return row_end - row_begin; }
+  int pos_rows() const { return (n + 3) & ~3; }  // position buffers hold the padding points too
 
   ~topolow_session() {
     for (auto& pr : prof_stage) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -192,14 +198,17 @@ using CfgB = StageCfg<512, 2, 1024>;   // 16 rows / WG, twice the waves
 using CfgC = StageCfg<512, 2, 2560>;   // whole 10k/4 slab in one LDS image
 using CfgD = StageCfg<256, 2, 1024>;   // 8 rows / WG
 using CfgE = StageCfg<512, 4, 1024>;   // 32 rows / WG
-using CfgF = StageCfg<256, 2, 1024, 1>;      // D + upfront loads
+using CfgF = StageCfg<256, 2, 1024, 2>;      // D + one-group-ahead prefetch
+using CfgI = StageCfg<256, 2, 1024, 0, 0, 8>;   // D squeezed to 64 VGPRs
+using CfgJ = StageCfg<256, 2, 1024, 0, 0, 6>;   // D squeezed to 80 VGPRs
+using CfgK = StageCfg<256, 2, 1024, 0, 0, 5>;   // D squeezed to 96 VGPRs
 using CfgG = StageCfg<256, 2, 1024, 0, 1>;   // D, memory only (tuning)
 using CfgH = StageCfg<256, 2, 1024, 0, 2>;   // D, arithmetic only (tuning)
 
 int slab_variant() {
   static int v = [] {
     const char* e = getenv("TOPOLOW_SLAB_VARIANT");
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 10;
   }();
   return v;
 }
@@ -209,18 +218,17 @@ void launch_stage_cfg(topolow_session* s, const void* pin, void* pout, RunState*
                       SlabRanges rg, int iter1, double k) {
   const int blocks = (s->rows() + CFG::ROWS - 1) / CFG::ROWS;
   const size_t lds = sizeof(real) * DIM * CFG::CHUNK;
-  auto kern = &slab_stage_kernel<DIM, real, CFG>;
-  if (lds > 64 * 1024) {
-    static bool raised = false;
-    if (!raised) {
+  auto launch = [&](auto kern) {
+    if (lds > 64 * 1024) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      raised = true;
     }
-  }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), lds, s->stream, s->enc.p, s->ld,
-                     s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
-                     s->rowflags.p, st, rg, iter1, k, s->c_rep);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), lds, s->stream, s->enc.p, s->ld,
+                       s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
+                       s->rowflags.p, st, rg, iter1, k, s->c_rep);
+  };
+  if (s->any_threshold) launch(&slab_stage_kernel<DIM, real, CFG, true>);
+  else launch(&slab_stage_kernel<DIM, real, CFG, false>);
 }
 
 template <int DIM>
@@ -239,6 +247,9 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
       case 5: launch_stage_cfg<DIM, float, CfgF>(s, pin, pout, st, rg, iter1, k); break;
       case 6: launch_stage_cfg<DIM, float, CfgG>(s, pin, pout, st, rg, iter1, k); break;
       case 7: launch_stage_cfg<DIM, float, CfgH>(s, pin, pout, st, rg, iter1, k); break;
+      case 8: launch_stage_cfg<DIM, float, CfgI>(s, pin, pout, st, rg, iter1, k); break;
+      case 9: launch_stage_cfg<DIM, float, CfgJ>(s, pin, pout, st, rg, iter1, k); break;
+      case 10: launch_stage_cfg<DIM, float, CfgK>(s, pin, pout, st, rg, iter1, k); break;
       default: launch_stage_cfg<DIM, float, CfgB>(s, pin, pout, st, rg, iter1, k); break;
     }
   }
@@ -246,9 +257,33 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
   s->stage_launches += 1;
 }
 
+using ErrCfg = StageCfg<256, 2, 1024>;
+
+template <int DIM, typename real>
+void launch_dense_error(topolow_session* s, const void* pos, const RunState* st) {
+  const size_t lds = sizeof(real) * DIM * ErrCfg::CHUNK;
+  if (s->dense_parity) {
+    hipLaunchKernelGGL((dense_error_kernel<DIM, real, ErrCfg, true>), dim3(s->dense_blocks),
+                       dim3(ErrCfg::THREADS), lds, s->stream, s->enc.p, s->ld, s->row_begin,
+                       s->row_end, s->n, (const real*)pos, s->rowflags.p, s->part_sum.p,
+                       s->part_cnt.p, st);
+  } else {
+    hipLaunchKernelGGL((dense_error_kernel<DIM, real, ErrCfg, false>), dim3(s->dense_blocks),
+                       dim3(ErrCfg::THREADS), lds, s->stream, s->enc.p, s->ld, s->row_begin,
+                       s->row_end, s->n, (const real*)pos, s->rowflags.p, s->part_sum.p,
+                       s->part_cnt.p, st);
+  }
+}
+
+// Number of partial sums the last launched error kernel produced.
+int error_parts(const topolow_session* s) { return s->dense_mae ? s->dense_blocks : s->n_parts; }
+
 template <int DIM>
 void launch_edge_error(topolow_session* s, const void* pos, const RunState* st) {
-  if (s->precision == TOPOLOW_PRECISION_F64) {
+  if (s->dense_mae) {
+    if (s->precision == TOPOLOW_PRECISION_F64) launch_dense_error<DIM, double>(s, pos, st);
+    else launch_dense_error<DIM, float>(s, pos, st);
+  } else if (s->precision == TOPOLOW_PRECISION_F64) {
     hipLaunchKernelGGL((edge_error_kernel<DIM, double, double>), dim3(s->n_parts),
                        dim3(kThreads), 0, s->stream, (const double*)pos, s->ei.p, s->ej.p,
                        (const double*)s->et.p, s->ec.p, s->n_edges, s->part_sum.p,
@@ -264,12 +299,12 @@ void launch_edge_error(topolow_session* s, const void* pos, const RunState* st) 
 void launch_controller(topolow_session* s, const void* pos, int iter1, double k_after) {
   const long long nv = (long long)s->n * s->dim;
   if (s->precision == TOPOLOW_PRECISION_F64) {
-    hipLaunchKernelGGL((controller_kernel<double>), dim3(1), dim3(kThreads), 0, s->stream,
-                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, s->n_parts,
+    hipLaunchKernelGGL((controller_kernel<double>), dim3(1), dim3(kCtlThreads), 0, s->stream,
+                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, error_parts(s),
                        (const double*)pos, (double*)s->best.p, nv, iter1, k_after);
   } else {
-    hipLaunchKernelGGL((controller_kernel<float>), dim3(1), dim3(kThreads), 0, s->stream,
-                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, s->n_parts,
+    hipLaunchKernelGGL((controller_kernel<float>), dim3(1), dim3(kCtlThreads), 0, s->stream,
+                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, error_parts(s),
                        (const float*)pos, (float*)s->best.p, nv, iter1, k_after);
   }
   HIP_TRY(hipGetLastError());
@@ -277,18 +312,21 @@ void launch_controller(topolow_session* s, const void* pos, int iter1, double k_
 
 // positions host (n x dim f64 column-major) <-> device (n x dim row-major, session precision)
 void upload_positions(topolow_session* s, const double* host_colmajor, void* dst) {
-  const size_t nv = (size_t)s->n * s->dim;
+  // rows [n, roundup4(n)) are the phantom points of the padding columns (relax_common.h)
+  const size_t nv = (size_t)s->pos_rows() * s->dim;
   if (s->precision == TOPOLOW_PRECISION_F64) {
-    std::vector<double> tmp(nv);
+    std::vector<double> tmp(nv, 0.0);
     for (int i = 0; i < s->n; ++i)
       for (int d = 0; d < s->dim; ++d) tmp[(size_t)i * s->dim + d] = host_colmajor[i + (size_t)d * s->n];
+    for (int i = s->n; i < s->pos_rows(); ++i) tmp[(size_t)i * s->dim] = kFarF64;
     HIP_TRY(hipMemcpyAsync(dst, tmp.data(), nv * 8, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   } else {
-    std::vector<float> tmp(nv);
+    std::vector<float> tmp(nv, 0.0f);
     for (int i = 0; i < s->n; ++i)
       for (int d = 0; d < s->dim; ++d)
         tmp[(size_t)i * s->dim + d] = (float)host_colmajor[i + (size_t)d * s->n];
+    for (int i = s->n; i < s->pos_rows(); ++i) tmp[(size_t)i * s->dim] = kFarF32;
     HIP_TRY(hipMemcpyAsync(dst, tmp.data(), nv * 4, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
@@ -318,6 +356,10 @@ void compute_row_flags(topolow_session* s) {
                      s->rows(), s->ld, s->rowflags.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<unsigned char> h(s->rows());
+  HIP_TRY(hipMemcpy(h.data(), s->rowflags.p, h.size(), hipMemcpyDeviceToHost));
+  s->any_threshold = false;
+  for (unsigned char f : h) s->any_threshold = s->any_threshold || f != 0;
 }
 
 void upload_degrees(topolow_session* s, const int32_t* degrees) {
@@ -469,7 +511,7 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     s->stream = s->own_stream;
     s->enc.alloc((size_t)s->rows() * s->ld);
-    const size_t pos_bytes = (size_t)n * ndim * s->real_size();
+    const size_t pos_bytes = (size_t)s->pos_rows() * ndim * s->real_size();
     s->pos[0].alloc(pos_bytes);
     s->pos[1].alloc(pos_bytes);
     s->best.alloc(pos_bytes);
@@ -592,8 +634,45 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     s->n_parts = (int)blocks;
-    s->part_sum.alloc(s->n_parts);
-    s->part_cnt.alloc(s->n_parts);
+    // upper-triangle mode folds two rows per wave; parity mode takes RPW consecutive rows
+    s->dense_blocks = (s->rows() + ErrCfg::ROWS - 1) / ErrCfg::ROWS + 1;
+    s->part_sum.alloc(std::max(s->n_parts, s->dense_blocks));
+    s->part_cnt.alloc(std::max(s->n_parts, s->dense_blocks));
+    // Can the MAE be reduced from the encoded block instead of gathering the edge list?  Only if
+    // the list is exactly the set of measured cells the dense pass would visit.
+    s->dense_mae = false;
+    s->dense_parity = !(s->row_begin == 0 && s->row_end == s->n);
+    const char* force = getenv("TOPOLOW_EDGE_MAE");
+    if (s->gplus.p && !(force && atoi(force) != 0)) {
+      unsigned long long fp = 0;
+      bool owned = true;
+      for (size_t e = 0; e < m && owned; ++e) {
+        const int a = edge_i[e], b = edge_j[e];
+        if (a < 0 || b < 0 || a >= s->n || b >= s->n || a == b) { owned = false; break; }
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        int owner = lo;
+        if (s->dense_parity && (((lo + hi) & 1) != 0)) owner = hi;
+        if (owner < s->row_begin || owner >= s->row_end) { owned = false; break; }
+        const uint32_t w = encode_target(edge_dist[e], edge_thresh[e]);
+        if (w == kInfWord) { owned = false; break; }
+        fp += cell_fingerprint(lo, hi, w);
+      }
+      if (owned) {
+        DevBuf<unsigned long long> d_fp;
+        d_fp.alloc(2);
+        HIP_TRY(hipMemset(d_fp.p, 0, 16));
+        hipLaunchKernelGGL(upper_fingerprint_kernel, dim3(s->rows()), dim3(kThreads), 0, s->stream,
+                           s->enc.p, s->n, s->row_begin, s->row_end, s->ld, s->dense_parity ? 1 : 0,
+                           d_fp.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        unsigned long long h[2];
+        HIP_TRY(hipMemcpy(h, d_fp.p, 16, hipMemcpyDeviceToHost));
+        // parity (f64) sessions keep the exact f64 edge targets
+        s->dense_mae = (h[0] == fp) && (h[1] == (unsigned long long)m) &&
+                       s->precision == TOPOLOW_PRECISION_F32;
+      }
+    }
   });
 }
 
@@ -604,6 +683,9 @@ int topolow_session_set_positions(topolow_session* s, const double* positions, c
     HIP_TRY(hipSetDevice(s->device));
     s->cur = 0;
     upload_positions(s, positions, s->pos[0].p);
+    // the other ping-pong buffer needs the same padding rows
+    HIP_TRY(hipMemcpy(s->pos[1].p, s->pos[0].p, (size_t)s->pos_rows() * s->dim * s->real_size(),
+                      hipMemcpyDeviceToDevice));
   });
 }
 
@@ -651,8 +733,9 @@ int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double 
     *s->mailbox = st;
     HIP_TRY(hipMemcpyAsync(s->state.p, &st, sizeof st, hipMemcpyHostToDevice, s->stream));
     // best snapshot starts as the initial positions (reference :171)
-    HIP_TRY(hipMemcpyAsync(s->best.p, s->pos[s->cur].p, (size_t)s->n * s->dim * s->real_size(),
-                           hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->best.p, s->pos[s->cur].p,
+                           (size_t)s->pos_rows() * s->dim * s->real_size(), hipMemcpyDeviceToDevice,
+                           s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   });
 }
@@ -780,6 +863,12 @@ int topolow_session_set_stream(topolow_session* s, void* hip_stream, int32_t ext
 
 void* topolow_session_stream(topolow_session* s) { return s ? (void*)s->stream : nullptr; }
 
+int32_t topolow_session_position_rows(const topolow_session* s) { return s ? s->pos_rows() : 0; }
+
+int32_t topolow_session_uses_dense_mae(const topolow_session* s) {
+  return s && s->dense_mae ? 1 : 0;
+}
+
 int64_t topolow_session_stage_launches(const topolow_session* s) {
   return s ? s->stage_launches : 0;
 }
@@ -810,16 +899,15 @@ int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* su
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
     TL_DISPATCH_DIM(s->dim, launch_edge_error, s, d_pos, (const RunState*)nullptr);
-    std::vector<double> ps(s->n_parts);
-    std::vector<unsigned long long> pc(s->n_parts);
-    HIP_TRY(hipMemcpyAsync(ps.data(), s->part_sum.p, s->n_parts * 8, hipMemcpyDeviceToHost,
-                           s->stream));
-    HIP_TRY(hipMemcpyAsync(pc.data(), s->part_cnt.p, s->n_parts * 8, hipMemcpyDeviceToHost,
-                           s->stream));
+    const int np = error_parts(s);
+    std::vector<double> ps(np);
+    std::vector<unsigned long long> pc(np);
+    HIP_TRY(hipMemcpyAsync(ps.data(), s->part_sum.p, np * 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(pc.data(), s->part_cnt.p, np * 8, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     double ts = 0.0;
     unsigned long long tc = 0;
-    for (int p = 0; p < s->n_parts; ++p) { ts += ps[p]; tc += pc[p]; }
+    for (int p = 0; p < np; ++p) { ts += ps[p]; tc += pc[p]; }
     if (sum) *sum = ts;
     if (count) *count = (int64_t)tc;
   });

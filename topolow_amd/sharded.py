@@ -125,7 +125,11 @@ class HipBackend:
         self.session.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     def new_positions(self, rows_total):
-        return self.torch.zeros((rows_total, self.ndim), dtype=self.torch.float32, device=self.device)
+        # at least roundup4(n) rows; rows >= n are the padding columns' phantom points
+        rows = max(rows_total, self.session.position_rows)
+        t = self.torch.zeros((rows, self.ndim), dtype=self.torch.float32, device=self.device)
+        t[self.n:, 0] = _native.FAR_F32
+        return t
 
     def to_device(self, pos_np, rows_total):
         t = self.new_positions(rows_total)
