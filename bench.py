@@ -113,6 +113,17 @@ def run_single(args):
     s.set_profiling(False)
     s.sync()
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC run of this same
+    # command (profiles/: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, per launch); null if absent.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
+            for name, vals in json.load(fh).items():
+                if "slab_stage_kernel<5, float" in name and "hbm_traffic_bytes_per_launch" in vals:
+                    traffic = vals["hbm_traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     bytes_iter = s.bytes_per_iteration
     stages_per_iter = stage_launches / K
     bytes_per_launch = bytes_iter / stages_per_iter
@@ -137,7 +148,9 @@ def run_single(args):
                    "n_points": n, "ndim": ndim, "schedule": "slab", "stages_per_iteration": stages_per_iter,
                    "edges": int(call.edge_i.size), "mae_pass": "dense" if s.uses_dense_mae else "edges"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                       "separate passes, FETCH_SIZE x2 on gfx950)" if traffic else None,
                      "kernel": "slab_stage_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "check_us": (check_ms * 1e3 / checks) if checks else None},

@@ -69,6 +69,18 @@ __device__ __forceinline__ real wave_sum(real v) {
   return v;
 }
 
+// One encoded row as a buffer resource (wave-uniform, lives in 4 SGPRs): loads then need only a
+// 32-bit lane offset instead of a 64-bit address per row.
+typedef __amdgpu_buffer_rsrc_t row_rsrc_t;
+__device__ __forceinline__ row_rsrc_t make_row_rsrc(const uint32_t* row, int ld) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), /*stride*/ 0, ld * 4, 0x00020000);
+}
+__device__ __forceinline__ uint4 load_words(row_rsrc_t rsrc, int byte_off) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Stage the points of columns [cb, cb+cw) into LDS as they lie in HBM (row-major n4 x DIM, so a
 // chunk is one contiguous run): a straight 16-byte-per-lane copy, all of a lane's loads in
 // flight before its first LDS write.  Position buffers hold roundup4(n) rows; the padding rows
@@ -196,6 +208,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_kernel
     cg[r] = uniform((real)(0.5 * c_rep) / g);
     rowp[r] = denc + (size_t)(rr - row_begin) * ld;
   }
+  row_rsrc_t rsrc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) rsrc[r] = make_row_rsrc(rowp[r], ld);
   const bool thr = ANYTHR && __builtin_amdgcn_readfirstlane(thr_any) != 0;
 
 #pragma unroll 1
@@ -297,7 +312,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_kernel
             if constexpr (CFG::ABLATE == 2) {
               w4[r] = make_uint4(0x40000000u + c4, 0x40400002u, 0x7f800002u, 0x40800001u);
             } else {
-              w4[r] = *reinterpret_cast<const uint4*>(rowp[r] + cb + c4);
+              // buffer load: per-row descriptor in SGPRs + one shared 32-bit lane offset
+              w4[r] = load_words(rsrc[r], (cb + c4) * 4);
             }
           }
           if constexpr (CFG::ABLATE == 1) {
@@ -428,6 +444,9 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
     for (int d = 0; d < DIM; ++d) pi[r][d] = uniform(pos[(size_t)rr * DIM + d]);
     rowp[r] = denc + (size_t)(rr - row_begin) * ld;
   }
+  row_rsrc_t rsrc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) rsrc[r] = make_row_rsrc(rowp[r], ld);
   const bool thr = __builtin_amdgcn_readfirstlane(thr_any) != 0;
 
   float err = 0.0f;
@@ -450,7 +469,7 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
       for (int r = 0; r < RPW; ++r) {
         const int i = rows[r];
         if (!PARITY && col + 3 <= i) continue;  // whole group left of the diagonal (wave-varying, cheap)
-        const uint4 w4 = *reinterpret_cast<const uint4*>(rowp[r] + col);
+        const uint4 w4 = load_words(rsrc[r], col * 4);
         bool take[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
