@@ -93,6 +93,39 @@ int topolow_optimize_layout_exact(
     double* positions_out, int32_t* converged, int32_t* iterations, double* final_mae,
     double* final_k, topolow_run_stats* stats, char* errbuf, size_t errlen);
 
+/* Batch form: `count` independent embeddings in one call -- one workgroup per embedding on the
+ * exact Gauss-Seidel kernel (the reference's only parallel mode is one embedding per forked
+ * process: R/adaptive_sampling.R:666,1301; its CV evaluator `likelihood_function`,
+ * R/adaptive_sampling.R:2552-2726, runs `folds` such embeddings per parameter set).  Problems may
+ * differ in every field, ndim included.  A problem that fails (e.g. non-finite positions) gets
+ * its own error_code / message-free status; the call itself still returns TOPOLOW_OK. */
+typedef struct topolow_problem {
+  const double* initial_positions;     /* n x ndim, column-major */
+  const double* dissimilarity_matrix;  /* n x n, +Inf = unmeasured */
+  const int32_t* threshold_matrix;     /* n x n */
+  const int32_t* degrees;              /* n */
+  const int32_t* edge_i;
+  const int32_t* edge_j;
+  const double* edge_dist;
+  const int32_t* edge_thresh;
+  int64_t n_edges;
+  int32_t n, ndim, n_iter, convergence_window, convergence_check_freq, reserved0;
+  double k0, cooling_rate, c_repulsion, relative_epsilon;
+  uint64_t seed;
+} topolow_problem;
+
+typedef struct topolow_result {
+  double* positions_out;               /* n x ndim, column-major, caller-allocated */
+  double final_mae, final_k;
+  int32_t converged, iterations, iterations_run, n_checks;
+  int32_t error_code;                  /* TOPOLOW_OK or TOPOLOW_ERR_NONFINITE */
+  int32_t error_iteration;             /* iteration reported by the non-finite guard */
+} topolow_result;
+
+int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow_result* results,
+                                        int32_t count, int32_t precision, int32_t device,
+                                        double* device_seconds, char* errbuf, size_t errlen);
+
 /* Replaces `as.matrix(stats::dist(positions))` (reference R/core.R:474):
  * positions n x ndim float64 column-major (host) -> est_distances n x n float64 (host). */
 int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,

@@ -1,0 +1,106 @@
+"""Input construction (topolow_amd/antigenic.py) and the CV evaluator's host logic
+(topolow_amd/cv.py) against the reference's semantics (R/data_preprocessing.R:488-844,
+R/error_metrics.R:55-144, R/adaptive_sampling.R:2570-2598) -- CPU only."""
+import csv
+import math
+import os
+
+import numpy as np
+import pytest
+
+from topolow_amd import antigenic, core, cv
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_similarity_titers_to_distances_and_threshold_inversion():
+    rows = [dict(v="A", s="X", titer="320", vy=2000, sy=2001),
+            dict(v="B", s="X", titer="<10", vy=2001, sy=2001),
+            dict(v="B", s="Y", titer="80", vy=2001, sy=2002),
+            dict(v="A", s="Y", titer=">1280", vy=2000, sy=2002),
+            dict(v="A", s="Y", titer="bad", vy=2000, sy=2002),
+            dict(v="C", s="Y", titer="", vy=2003, sy=2002)]
+    long_rows, m = antigenic.process_antigenic_data(rows, "v", "s", "titer", is_similarity=True, base=2,
+                                                    scale_factor=10, antigen_year_col="vy", serum_year_col="sy")
+    d = {(r["v"], r["s"]): r["distance"] for r in long_rows}
+    # serum X: log2(32)=5, log2(1)=0 -> max 5 ; serum Y: log2(8)=3, log2(128)=7 -> max 7
+    assert d[("A", "X")] == "0" and d[("B", "X")] == ">5"       # "<" titer -> ">" distance
+    assert d[("B", "Y")] == "4" and d[("A", "Y")] == "<0"       # ">" titer -> "<" distance
+    assert m.names == ["V/A", "S/X", "V/B", "S/Y"]    # by year (stable over the sorted names), V/ S/ prefixes
+    v = m.values
+    ix = {nm: q for q, nm in enumerate(m.names)}
+    assert v[ix["V/A"], ix["S/X"]] == "0" and v[ix["S/X"], ix["V/A"]] == "0"
+    assert v[ix["V/B"], ix["S/X"]] == ">5" and v[0, 0] == "0"
+    assert v[ix["V/A"], ix["V/B"]] is None and v[ix["S/X"], ix["S/Y"]] is None   # no antigen-antigen cells
+
+
+def test_repeated_measurements_average_and_keep_sign():
+    rows = [dict(v="A", s="X", titer="4"), dict(v="A", s="X", titer="<16"), dict(v="B", s="X", titer="64")]
+    long_rows, _ = antigenic.process_antigenic_data(rows, "v", "s", "titer", is_similarity=True, base=2,
+                                                    antigen_year_col=None, serum_year_col=None)
+    d = {(r["v"], r["s"]): r["distance"] for r in long_rows}
+    # distances 6-2=4 and ">"(6-4)=">2" -> mean 3, any "<"/">" -> sign: "<" if any "<" else ">"
+    assert d[("A", "X")] == ">3" and d[("B", "X")] == "0"
+
+
+def test_dissimilarity_mode_log1p():
+    rows = [dict(v="A", s="X", ic50="1.718281828459045"), dict(v="B", s="X", ic50=">50")]
+    long_rows, _ = antigenic.process_antigenic_data(rows, "v", "s", "ic50", antigen_year_col=None,
+                                                    serum_year_col=None)
+    d = {(r["v"], r["s"]): r["distance"] for r in long_rows}
+    assert float(d[("A", "X")]) == pytest.approx(1.0) and d[("B", "X")].startswith(">")
+    assert float(d[("B", "X")][1:]) == pytest.approx(math.log(51.0))
+
+
+def test_h3n2_and_hiv_fixtures_have_the_surveyed_shape():
+    """H3N2 -> 285 points; HIV -> 335 points, 1249 thresholded rows."""
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "h3n2_distances.csv"))))
+    m = antigenic.titers_list_to_matrix(rows, "virusStrain", "virusYear", "serumStrain", "serumYear",
+                                        "distance", sort=True)
+    assert len(m.names) == 285 and sum(r["distance"].startswith(">") for r in rows) == 911
+    call = core.prepare_layout_call(m, 5, 10, 14.76214, 0.03641074, 0.002943064, 1e-4, 5, None, False, 3,
+                                    False, np.random.default_rng(0))
+    assert call.edge_i.size == len(rows) and int((call.edge_thresh == 1).sum()) == 911
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "hiv_distances.csv"))))
+    m = antigenic.titers_list_to_matrix(rows, "Virus", "virusYear", "Antibody", None, "distance", sort=True)
+    assert len(m.names) == 335 and sum(r["distance"][0] in "<>" for r in rows) == 1249
+
+
+def test_error_calculator_comparison_reference_cases():
+    """tests/testthat/test-edge-cases.R:84-109 and the documented behaviour."""
+    t = np.full((3, 3), 5.0); np.fill_diagonal(t, 0)
+    assert cv.error_calculator_comparison(t.copy(), t)["Completeness"] == 1
+    truth = np.array([[0, 1, 2], [1, 0, 3], [2, 3, 0]], float)
+    assert cv.error_calculator_comparison(np.full((3, 3), np.nan), truth)["Completeness"] == 0
+    pred = truth + 0.5
+    inp = truth.copy(); inp[0, 2] = inp[2, 0] = np.nan
+    e = cv.error_calculator_comparison(pred, truth, inp)
+    out = e["OutSampleError"]
+    assert np.sum(~np.isnan(out)) == 2 and np.allclose(out[~np.isnan(out)], -0.5)
+    assert np.sum(~np.isnan(e["InSampleError"])) == 7 and e["Completeness"] == 1
+    # threshold truths drop out (as.numeric -> NA, R/error_metrics.R:90-91)
+    tm = np.array([["0", ">2", "3"], [">2", "0", "4"], ["3", "4", "0"]], dtype=object)
+    im = tm.copy(); im[0, 1] = im[1, 0] = None; im[0, 2] = im[2, 0] = None
+    e = cv.error_calculator_comparison(np.ones((3, 3)), tm, im)
+    assert np.sum(~np.isnan(e["OutSampleError"])) == 2      # only the numeric "3" pair counts
+
+
+def test_fold_construction():
+    rng = np.random.default_rng(1)
+    d = rng.uniform(1, 5, (12, 12)); d = np.triu(d, 1); d = d + d.T
+    d[0, 5] = d[5, 0] = np.nan
+    folds = cv.make_folds(d, 4, rng)
+    size = int((~np.isnan(d)).sum()) // 8
+    assert len(folds) == 4 and all(f.size == size for f in folds)
+    # a draw may hold a cell AND its mirror (both are separate linear indices in the reference's
+    # pool, R/adaptive_sampling.R:2588); across folds the unordered pairs are disjoint
+    seen = set()
+    for f in folds:
+        assert len(set(f.tolist())) == f.size
+        mine = set()
+        for idx in f:
+            r, c = int(idx % 12), int(idx // 12)
+            assert not np.isnan(d[r, c])
+            mine.add((min(r, c), max(r, c)))
+        assert not (mine & seen)
+        seen |= mine

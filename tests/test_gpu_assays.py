@@ -1,0 +1,106 @@
+"""BASELINE configs 2 and 5 on the GPU (run with -m gpu):
+  config 2 -- Smith-2004 H3N2 HI panel (285 points, 911 censored titers), published parameters
+              (inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:312-316 of the reference), ndim 5
+              (BASELINE) and 4 (published): device GS kernel == oracle replay bit for bit, and the
+              MAE level agrees with the reference-order oracle.
+  config 5 -- HIV neutralisation panel (335 points, 1249 censored), k-fold CV evaluator
+              (`likelihood_function`) as ONE batched launch; the pooled hold-out MAE is compared with
+              the numbers the reference publishes for exactly this pipeline
+              (inst/examples/comparison_results/error_summary.csv: H3N2 0.799, HIV 1.315).
+The matrices come from tests/golden/*.csv (built from the reference's data files by
+tests/golden/make_assay_fixtures.py)."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from oracle import topolow_oracle as orc
+from tests.conftest import layout_call_args
+from topolow_amd import _native, antigenic, core, cv
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+H3N2 = dict(k0=14.76214, cooling_rate=0.03641074, c_repulsion=0.002943064)
+HIV = dict(N=2, k0=3.550036, cooling_rate=0.04130713, c_repulsion=0.0007038619)
+
+
+def h3n2_matrix():
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "h3n2_distances.csv"))))
+    return antigenic.titers_list_to_matrix(rows, "virusStrain", "virusYear", "serumStrain", "serumYear",
+                                           "distance", sort=True)
+
+
+def hiv_matrix():
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "hiv_distances.csv"))))
+    return antigenic.titers_list_to_matrix(rows, "Virus", "virusYear", "Antibody", None, "distance", sort=True)
+
+
+@pytest.mark.parametrize("ndim", [5, 4])
+def test_config2_h3n2_gs_equals_oracle_replay(ndim):
+    m = h3n2_matrix()
+    call = core.prepare_layout_call(m, ndim, 1000, H3N2["k0"], H3N2["cooling_rate"], H3N2["c_repulsion"],
+                                    1e-4, 5, None, False, 3, False, np.random.default_rng(7))
+    n = call.initial_positions.shape[0]
+    assert n == 285
+    seed = 2004
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed)   # AUTO -> gs, f64
+    assert got.info["schedule"] == "gs" and got.info["precision"] == "f64"
+
+    def order_fn(it, arr):
+        arr[:] = _native.gs_pair_order(n, seed, it)
+    ref = orc.optimize_layout_exact(*layout_call_args(call), order_mode=orc.ORDER_SUPPLIED, order_fn=order_fn)
+    assert got.converged == ref.converged and got.iterations == ref.iterations
+    assert np.abs(got.positions - ref.positions).max() <= 1e-10
+    assert got.final_mae == pytest.approx(ref.final_mae, rel=1e-10)
+    # the reference-order (std::shuffle) oracle lands at the same error level
+    shuf = [orc.optimize_layout_exact(*layout_call_args(call), seed=s).final_mae for s in range(5)]
+    assert abs(got.final_mae - np.mean(shuf)) <= max(4 * np.std(shuf), 0.05 * np.mean(shuf))
+
+
+def test_config2_slab_schedule_on_h3n2_when_forced():
+    """The slab schedule on a small, 91 %-sparse, heavily censored panel: same error level."""
+    m = h3n2_matrix()
+    call = core.prepare_layout_call(m, 5, 1000, H3N2["k0"], H3N2["cooling_rate"], H3N2["c_repulsion"],
+                                    1e-4, 5, None, False, 3, False, np.random.default_rng(7))
+    gs = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=s, schedule="gs").final_mae
+          for s in range(6)]
+    slab = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=s, schedule="slab").final_mae
+            for s in range(6)]
+    assert abs(np.mean(slab) - np.mean(gs)) <= max(4 * np.std(gs), 0.08 * np.mean(gs))
+
+
+def test_config5_batched_cv_matches_published_holdout_mae():
+    rng = np.random.default_rng(11)
+    h3 = h3n2_matrix()
+    res, secs, n_emb = cv.likelihood_sweep(h3, [dict(N=4, **H3N2)], 500, 1e-4, folds=20, rng=rng)
+    r = res[0]
+    assert n_emb == 20 and r["pct_converged"] >= 50
+    assert 0.65 <= r["Holdout_MAE"] <= 0.95, r          # reference publishes 0.799 (20-fold CV)
+    hv = hiv_matrix()
+    res, secs, n_emb = cv.likelihood_sweep(hv, [HIV], 500, 1e-4, folds=20, rng=rng)
+    r = res[0]
+    assert n_emb == 20
+    assert 1.05 <= r["Holdout_MAE"] <= 1.60, r          # reference publishes 1.315 (20-fold CV)
+    assert np.isfinite(r["NLL"]) and 0 < r["mean_iter"] <= 500
+
+
+def test_config5_sweep_many_parameter_sets_in_one_launch():
+    """A slice of an Euclidify-style sweep: 12 parameter sets x 5 folds = 60 embeddings, mixed
+    ndim, one call.  Every set must come back finite and the batch must agree with running one of
+    its members alone (same seed)."""
+    rng = np.random.default_rng(3)
+    hv = hiv_matrix()
+    sets = [dict(N=int(rng.integers(2, 7)), k0=float(rng.uniform(1, 12)),
+                 cooling_rate=float(rng.uniform(0.01, 0.06)), c_repulsion=float(rng.uniform(1e-4, 1e-2)))
+            for _ in range(12)]
+    res, secs, n_emb = cv.likelihood_sweep(hv, sets, 300, 1e-4, folds=5, rng=rng)
+    assert n_emb == 60 and len(res) == 12 and secs > 0
+    assert all(np.isfinite(r["Holdout_MAE"]) for r in res)
+    # batch member == the same problem run alone
+    call = core.prepare_layout_call(hv, 3, 200, 4.0, 0.03, 0.001, 1e-4, 5, None, False, 3, False,
+                                    np.random.default_rng(5))
+    alone = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=99, schedule="gs")
+    batch, _ = _native.optimize_layout_exact_batch([call, call], seeds=[99, 100])
+    assert np.array_equal(batch[0].positions, alone.positions) and batch[0].iterations == alone.iterations
+    assert not np.array_equal(batch[1].positions, alone.positions)

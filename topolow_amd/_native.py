@@ -47,6 +47,24 @@ class TopolowRunStats(C.Structure):
                 ("stage_launches", C.c_int64), ("reserved", C.c_int64 * 4)]
 
 
+class TopolowProblem(C.Structure):
+    _fields_ = [("initial_positions", C.POINTER(C.c_double)), ("dissimilarity_matrix", C.POINTER(C.c_double)),
+                ("threshold_matrix", C.POINTER(C.c_int32)), ("degrees", C.POINTER(C.c_int32)),
+                ("edge_i", C.POINTER(C.c_int32)), ("edge_j", C.POINTER(C.c_int32)),
+                ("edge_dist", C.POINTER(C.c_double)), ("edge_thresh", C.POINTER(C.c_int32)),
+                ("n_edges", C.c_int64), ("n", C.c_int32), ("ndim", C.c_int32), ("n_iter", C.c_int32),
+                ("convergence_window", C.c_int32), ("convergence_check_freq", C.c_int32),
+                ("reserved0", C.c_int32), ("k0", C.c_double), ("cooling_rate", C.c_double),
+                ("c_repulsion", C.c_double), ("relative_epsilon", C.c_double), ("seed", C.c_uint64)]
+
+
+class TopolowResult(C.Structure):
+    _fields_ = [("positions_out", C.POINTER(C.c_double)), ("final_mae", C.c_double),
+                ("final_k", C.c_double), ("converged", C.c_int32), ("iterations", C.c_int32),
+                ("iterations_run", C.c_int32), ("n_checks", C.c_int32), ("error_code", C.c_int32),
+                ("error_iteration", C.c_int32)]
+
+
 # Additive backend options (the reference's function signatures stay untouched; this mirrors
 # what an R user would set through options(topolow.*)).
 options: Dict[str, Any] = dict(seed=None, schedule="auto", precision="auto", slab_stages=0,
@@ -90,6 +108,10 @@ def load() -> C.CDLL:
         C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
         C.c_int32, C.POINTER(TopolowOptions), dp, ip, ip, dp, dp, C.POINTER(TopolowRunStats),
         C.c_char_p, C.c_size_t]
+    lib.topolow_optimize_layout_exact_batch.restype = C.c_int
+    lib.topolow_optimize_layout_exact_batch.argtypes = [C.POINTER(TopolowProblem), C.POINTER(TopolowResult),
+                                                        C.c_int32, C.c_int32, C.c_int32, dp, C.c_char_p,
+                                                        C.c_size_t]
     lib.topolow_est_distances.restype = C.c_int
     lib.topolow_est_distances.argtypes = [dp, C.c_int32, C.c_int32, dp, C.c_int32, C.c_char_p,
                                           C.c_size_t]
@@ -261,6 +283,55 @@ def optimize_layout_exact(call) -> NativeResult:
         call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.n_iter, call.k0,
         call.cooling_rate, call.c_repulsion, call.relative_epsilon, call.convergence_window,
         call.convergence_check_freq, call.verbose)
+
+
+def optimize_layout_exact_batch(calls, seeds=None, precision="f64", device=-1):
+    """Relaxes a list of core.LayoutCall objects as ONE grid of the exact-GS kernel (one workgroup
+    per embedding).  Returns (list of NativeResult-or-NativeError, device_seconds)."""
+    lib = load()
+    count = len(calls)
+    probs = (TopolowProblem * count)()
+    ress = (TopolowResult * count)()
+    keep = []
+    outs = []
+    for b, c in enumerate(calls):
+        pos0 = _f64F(c.initial_positions)
+        n, dim = pos0.shape
+        D, T = _f64F(c.dissimilarity_matrix), _i32F(c.threshold_matrix)
+        deg = np.ascontiguousarray(c.degrees, dtype=np.int32)
+        ei = np.ascontiguousarray(c.edge_i, dtype=np.int32)
+        ej = np.ascontiguousarray(c.edge_j, dtype=np.int32)
+        ed = np.ascontiguousarray(c.edge_dist, dtype=np.float64)
+        et = np.ascontiguousarray(c.edge_thresh, dtype=np.int32)
+        out = np.zeros((n, dim), dtype=np.float64, order="F")
+        keep.append((pos0, D, T, deg, ei, ej, ed, et))
+        outs.append(out)
+        p = probs[b]
+        p.initial_positions, p.dissimilarity_matrix, p.threshold_matrix = _dp(pos0), _dp(D), _ip(T)
+        p.degrees, p.edge_i, p.edge_j, p.edge_dist, p.edge_thresh = _ip(deg), _ip(ei), _ip(ej), _dp(ed), _ip(et)
+        p.n_edges, p.n, p.ndim, p.n_iter = int(ei.shape[0]), n, dim, int(c.n_iter)
+        p.convergence_window, p.convergence_check_freq = int(c.convergence_window), int(c.convergence_check_freq)
+        p.k0, p.cooling_rate, p.c_repulsion = float(c.k0), float(c.cooling_rate), float(c.c_repulsion)
+        p.relative_epsilon = float(c.relative_epsilon)
+        p.seed = int(seeds[b] if seeds is not None else _host_rng.integers(0, 2 ** 63 - 1)) & 0xFFFFFFFFFFFFFFFF
+        ress[b].positions_out = _dp(out)
+    secs = C.c_double(0.0)
+    err = C.create_string_buffer(512)
+    rc = lib.topolow_optimize_layout_exact_batch(probs, ress, count, _PRECISIONS[precision], int(device),
+                                                 C.byref(secs), err, len(err))
+    _check(rc, err)
+    results = []
+    for b in range(count):
+        r = ress[b]
+        if r.error_code != OK:
+            results.append(NativeError(r.error_code, "Numerical instability at iteration %d. Reduce k0 or "
+                                                     "c_repulsion." % r.error_iteration))
+        else:
+            results.append(NativeResult(np.ascontiguousarray(outs[b]), bool(r.converged), int(r.iterations),
+                                        float(r.final_mae), float(r.final_k),
+                                        dict(schedule="gs", precision=precision, iterations_run=r.iterations_run,
+                                             n_checks=r.n_checks, seed=int(probs[b].seed))))
+    return results, float(secs.value)
 
 
 def est_distances(positions) -> np.ndarray:

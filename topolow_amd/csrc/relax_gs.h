@@ -306,6 +306,7 @@ struct GsProblem {
 struct GsResult {
   double* positions;  // n x dim col-major (caller-owned)
   int converged, iterations, iters_run, n_checks;
+  int nonfinite_iter = 0;  // != 0: the non-finite guard fired at this iteration
   double final_mae, final_k;
 };
 
@@ -456,6 +457,7 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
         for (int d = 0; d < dim; ++d) res[b].positions[i + (size_t)d * p.n] = (double)pos[(size_t)i * dim + d];
       res[b].converged = o.converged; res[b].iterations = o.iterations; res[b].iters_run = o.iters_run;
       res[b].n_checks = o.n_checks; res[b].final_mae = o.final_mae; res[b].final_k = o.final_k;
+      res[b].nonfinite_iter = o.nonfinite_iter;
     }
   } catch (const GsHipError& e) {
     if (errbuf && errlen) snprintf(errbuf, errlen, "%s", e.msg.c_str());

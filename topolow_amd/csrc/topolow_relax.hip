@@ -913,6 +913,60 @@ int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* su
   });
 }
 
+// ---- batch of independent embeddings (GS kernel, one workgroup each) --------------------
+int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow_result* results,
+                                        int32_t count, int32_t precision, int32_t device,
+                                        double* device_seconds, char* errbuf, size_t errlen) {
+  if (count < 0 || (count > 0 && (!problems || !results))) return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (device_seconds) *device_seconds = 0.0;
+  if (count == 0) return TOPOLOW_OK;
+  const int prec = precision == TOPOLOW_PRECISION_F32 ? TOPOLOW_PRECISION_F32 : TOPOLOW_PRECISION_F64;
+  int rc_all = TOPOLOW_OK;
+  const int rc = guarded(errbuf, errlen, [&] {
+    select_device(device);
+    // the kernel is instantiated per ndim: run one grid per distinct ndim
+    std::vector<int> dims;
+    for (int b = 0; b < count; ++b) {
+      if (problems[b].n < 2) throw HipError{TOPOLOW_ERR_TOO_FEW_POINTS, "Need at least 2 points for embedding"};
+      if (std::find(dims.begin(), dims.end(), problems[b].ndim) == dims.end()) dims.push_back(problems[b].ndim);
+    }
+    for (int dim : dims) {
+      std::vector<GsProblem> pbs;
+      std::vector<GsResult> res;
+      std::vector<int> idx;
+      for (int b = 0; b < count; ++b) {
+        const topolow_problem& p = problems[b];
+        if (p.ndim != dim) continue;
+        GsProblem g;
+        g.initial_positions = p.initial_positions; g.D = p.dissimilarity_matrix; g.T = p.threshold_matrix;
+        g.degrees = p.degrees; g.edge_i = p.edge_i; g.edge_j = p.edge_j; g.edge_dist = p.edge_dist;
+        g.edge_thresh = p.edge_thresh; g.n_edges = p.n_edges; g.n = p.n; g.dim = p.ndim;
+        g.n_iter = p.n_iter; g.window = p.convergence_window; g.check_freq = p.convergence_check_freq;
+        g.k0 = p.k0; g.cooling = p.cooling_rate; g.c_rep = p.c_repulsion; g.eps = p.relative_epsilon;
+        g.seed = p.seed;
+        GsResult r;
+        r.positions = results[b].positions_out;
+        pbs.push_back(g); res.push_back(r); idx.push_back(b);
+      }
+      double secs = 0.0;
+      char local_err[256];
+      local_err[0] = 0;
+      const int rcb = gs_run_batch(pbs.data(), res.data(), (int)pbs.size(), prec, &secs, local_err,
+                                   sizeof local_err);
+      if (rcb != TOPOLOW_OK && rcb != TOPOLOW_ERR_NONFINITE) throw HipError{rcb, local_err};
+      if (device_seconds) *device_seconds += secs;
+      for (size_t q = 0; q < idx.size(); ++q) {
+        topolow_result& o = results[idx[q]];
+        o.final_mae = res[q].final_mae; o.final_k = res[q].final_k; o.converged = res[q].converged;
+        o.iterations = res[q].iterations; o.iterations_run = res[q].iters_run; o.n_checks = res[q].n_checks;
+        o.error_code = res[q].nonfinite_iter ? TOPOLOW_ERR_NONFINITE : TOPOLOW_OK;
+        o.error_iteration = res[q].nonfinite_iter;
+      }
+    }
+  });
+  return rc != TOPOLOW_OK ? rc : rc_all;
+}
+
 // ---- post metric -----------------------------------------------------------------------
 int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
                           double* est_distances, int32_t device, char* errbuf, size_t errlen) {
