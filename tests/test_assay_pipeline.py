@@ -89,7 +89,7 @@ def test_fold_construction():
     rng = np.random.default_rng(1)
     d = rng.uniform(1, 5, (12, 12)); d = np.triu(d, 1); d = d + d.T
     d[0, 5] = d[5, 0] = np.nan
-    folds = cv.make_folds(d, 4, rng)
+    folds = cv.make_folds(d.copy(), 4, rng)
     size = int((~np.isnan(d)).sum()) // 8
     assert len(folds) == 4 and all(f.size == size for f in folds)
     # a draw may hold a cell AND its mirror (both are separate linear indices in the reference's

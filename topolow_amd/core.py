@@ -103,6 +103,66 @@ def _strip_prefix(v: np.ndarray, mask: np.ndarray, pattern: str) -> np.ndarray:
                     dtype=np.float64)
 
 
+@dataclass
+class CodedMatrix:
+    """Numeric twin of R's character dissimilarity matrix: `values` holds the number of every
+    cell with any "<"/">" prefix stripped (NaN = NA), `codes` the prefix (0 none, 1 ">", -1 "<").
+    All of the driver's matrix logic runs on this form; strings are parsed once, up front."""
+    values: np.ndarray
+    codes: np.ndarray
+    names: Optional[List[str]] = None
+    character: bool = False   # was the source a character matrix? (is.character(), R/core.R:278)
+
+    def as_numeric(self) -> np.ndarray:
+        """as.numeric(matrix): threshold strings become NA."""
+        return np.where(self.codes == 0, self.values, np.nan)
+
+    def reordered(self, order: np.ndarray) -> "CodedMatrix":
+        ix = np.ix_(order, order)
+        return CodedMatrix(self.values[ix], self.codes[ix],
+                           [self.names[q] for q in order] if self.names is not None else None,
+                           self.character)
+
+    def masked(self, rows: np.ndarray, cols: np.ndarray) -> "CodedMatrix":
+        v, c = self.values.copy(), self.codes.copy()
+        v[rows, cols] = np.nan
+        v[cols, rows] = np.nan
+        c[rows, cols] = 0
+        c[cols, rows] = 0
+        return CodedMatrix(v, c, self.names, self.character)
+
+
+def coded_matrix(x: Any) -> Optional[CodedMatrix]:
+    """Any accepted matrix-like -> CodedMatrix (None if `x` is not a matrix in R's sense)."""
+    if isinstance(x, CodedMatrix):
+        return x
+    m = _as_rmatrix(x)
+    if m is None:
+        return None
+    v = m.values
+    if not _is_character(v):
+        vals = np.array(v, dtype=np.float64)
+        return CodedMatrix(vals, np.zeros(vals.shape, dtype=np.int8), m.names, False)
+    vals = np.full(v.shape, np.nan)
+    codes = np.zeros(v.shape, dtype=np.int8)
+    fv, fc = vals.reshape(-1), codes.reshape(-1)
+    for q, c in enumerate(v.reshape(-1)):
+        if _is_na_cell(c):
+            continue
+        if isinstance(c, str):
+            if c.startswith(">"):
+                fc[q] = 1
+                fv[q] = _as_numeric_scalar(c[1:])
+            elif c.startswith("<"):
+                fc[q] = -1
+                fv[q] = _as_numeric_scalar(c[1:])
+            else:
+                fv[q] = _as_numeric_scalar(c)
+        else:
+            fv[q] = _as_numeric_scalar(c)
+    return CodedMatrix(vals, codes, m.names, True)
+
+
 # --------------------------------------------------------------------------------------
 # result object (R/core.R:505-527) and its S3 methods (R/core.R:684-719)
 # --------------------------------------------------------------------------------------
@@ -186,7 +246,7 @@ class LayoutCall:
     # bookkeeping for the post-processing half
     names: Optional[List[str]] = None
     order: Optional[np.ndarray] = None            # permutation applied (None = identity)
-    reordered_matrix: Optional[np.ndarray] = None  # the (reordered) input matrix
+    reordered_matrix: Optional[Any] = None         # the (reordered) input as a CodedMatrix
 
 
 def _stop(msg: str):
@@ -197,7 +257,7 @@ def _is_number(x: Any) -> bool:
     return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
 
 
-def _validate(m: Optional[RMatrix], ndim, mapping_max_iter, k0, cooling_rate, c_repulsion,
+def _validate(m: Optional[CodedMatrix], ndim, mapping_max_iter, k0, cooling_rate, c_repulsion,
               relative_epsilon, convergence_counter, convergence_check_freq,
               initial_positions) -> None:
     """R/core.R:202-264, messages verbatim."""
@@ -206,7 +266,7 @@ def _validate(m: Optional[RMatrix], ndim, mapping_max_iter, k0, cooling_rate, c_
     v = m.values
     if v.shape[0] != v.shape[1]:
         _stop("dissimilarity_matrix must be square")
-    finite = _as_numeric(v).copy()
+    finite = m.as_numeric().copy()
     finite[np.isinf(finite)] = np.nan
     if int(np.sum(~np.isnan(finite) & (finite != 0))) == 0:
         warnings.warn("No finite non-zero dissimilarities found. Results may be unreliable.",
@@ -243,18 +303,13 @@ def _validate(m: Optional[RMatrix], ndim, mapping_max_iter, k0, cooling_rate, c_
         _stop("dissimilarity_matrix must have at least 2 rows/columns")
 
 
-def spectral_order(v: np.ndarray) -> Optional[np.ndarray]:
+def spectral_order(stripped: np.ndarray) -> Optional[np.ndarray]:
     """R/core.R:269-319: ascending order of each point's mean dissimilarity
     (mean of row mean and column mean over non-NA off-diagonal cells; threshold prefixes
-    stripped).  Returns None where the reference keeps the input order."""
-    n = v.shape[0]
+    stripped -- `stripped` is CodedMatrix.values).  Returns None where the reference keeps
+    the input order."""
     try:
-        non_na = ~_is_na(v)
-        numeric = np.full((n, n), np.nan)
-        if _is_character(v):
-            numeric[non_na] = _strip_prefix(v, non_na, r"^[<>]")
-        else:
-            numeric[non_na] = np.asarray(v, dtype=np.float64)[non_na]
+        numeric = np.array(stripped, dtype=np.float64)
         np.fill_diagonal(numeric, np.nan)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
@@ -274,28 +329,27 @@ def prepare_layout_call(dissimilarity_matrix, ndim, mapping_max_iter, k0, coolin
                         verbose, convergence_check_freq, preserve_order,
                         rng: Optional[np.random.Generator] = None) -> LayoutCall:
     """Everything `euclidean_embedding` does before the `.Call` (R/core.R:202-436)."""
-    m = _as_rmatrix(dissimilarity_matrix)
+    m = coded_matrix(dissimilarity_matrix)
     _validate(m, ndim, mapping_max_iter, k0, cooling_rate, c_repulsion, relative_epsilon,
               convergence_counter, convergence_check_freq, initial_positions)
-    v = m.values
     names = m.names
-    n = v.shape[0]
+    n = m.values.shape[0]
     ndim = int(ndim)
 
     # -- reordering (R/core.R:269-322)
     order = None
     if n > 1 and not preserve_order:
-        order = spectral_order(v)
+        order = spectral_order(m.values)
         if order is not None:
-            v = v[np.ix_(order, order)]
-            if names is not None:
-                names = [names[q] for q in order]
+            m = m.reordered(order)
+            names = m.names
             if verbose:
                 print("Matrix reordered for spectral pattern (largest values in corners)")
         elif verbose:
             print("Insufficient data for meaningful spectral ordering")
     elif preserve_order and verbose:
         print("Preserving original row/column order (preserve_order = TRUE)")
+    v = m
 
     # -- initial positions follow the matrix only through row names (R/core.R:325-333)
     init = None
@@ -310,31 +364,10 @@ def prepare_layout_call(dissimilarity_matrix, ndim, mapping_max_iter, k0, coolin
                 raise IndexError("subscript out of bounds") from None
 
     # -- degrees and parsing (R/core.R:340-374)
-    is_na = _is_na(v)
-    non_na = ~is_na
+    non_na = ~np.isnan(m.values)
     degrees = non_na.sum(axis=1).astype(np.int32)
-    distances = np.full((n, n), np.inf, dtype=np.float64)
-    codes = np.zeros((n, n), dtype=np.int32)
-    if _is_character(v):
-        starts_gt = np.zeros((n, n), dtype=bool)
-        starts_lt = np.zeros((n, n), dtype=bool)
-        for a in range(n):
-            for b in range(n):
-                if non_na[a, b]:
-                    s = str(v[a, b])
-                    starts_gt[a, b] = s.startswith(">")
-                    starts_lt[a, b] = s.startswith("<")
-        normal = non_na & ~starts_gt & ~starts_lt
-        codes[starts_gt] = 1
-        codes[starts_lt] = -1
-        if starts_gt.any():
-            distances[starts_gt] = _strip_prefix(v, starts_gt, r"^>")
-        if starts_lt.any():
-            distances[starts_lt] = _strip_prefix(v, starts_lt, r"^<")
-        if normal.any():
-            distances[normal] = np.array([_as_numeric_scalar(c) for c in v[normal]])
-    else:
-        distances[non_na] = np.asarray(v, dtype=np.float64)[non_na]
+    distances = np.where(non_na, m.values, np.inf)
+    codes = np.where(non_na, m.codes, 0).astype(np.int32)
 
     # -- COO edge list, upper triangle, column-major scan like which(arr.ind=TRUE)
     #    (R/core.R:383-402)
@@ -350,7 +383,7 @@ def prepare_layout_call(dissimilarity_matrix, ndim, mapping_max_iter, k0, coolin
 
     # -- initial positions (R/core.R:407-415)
     if init is None:
-        numeric = _as_numeric(v)
+        numeric = m.as_numeric()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
             init_step = np.nanmax(numeric) / n
@@ -377,9 +410,9 @@ def prepare_layout_call(dissimilarity_matrix, ndim, mapping_max_iter, k0, coolin
         names=names, order=order, reordered_matrix=v)
 
 
-def post_mae(reordered_matrix: np.ndarray, est_distances: np.ndarray) -> float:
+def post_mae(reordered_matrix, est_distances: np.ndarray) -> float:
     """R/core.R:479-481: mean |as.numeric(D) - est| over every non-NA cell."""
-    raw = _as_numeric(reordered_matrix)
+    raw = coded_matrix(reordered_matrix).as_numeric()
     valid = ~np.isnan(raw)
     if not valid.any():
         return float("nan")

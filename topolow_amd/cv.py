@@ -17,16 +17,20 @@ import numpy as np
 from . import _native, core
 
 
+def _numeric(x) -> np.ndarray:
+    """as.numeric(<matrix>): threshold strings -> NA."""
+    return core.coded_matrix(x).as_numeric()
+
+
 def error_calculator_comparison(predicted, true, input_=None, pred_names=None, true_names=None):
     """OutSampleError / InSampleError vectors and Completeness (R/error_metrics.R:55-144).
     Threshold strings become NA under as.numeric (:90-91) and therefore drop out."""
     pred = np.asarray(predicted, dtype=np.float64)
-    true_v = np.asarray(true.values if isinstance(true, core.RMatrix) else true)
-    inp = true if input_ is None else input_
-    inp_v = np.asarray(inp.values if isinstance(inp, core.RMatrix) else inp)
-    if pred.shape != true_v.shape or pred.shape != inp_v.shape:
+    truth_m = _numeric(true)
+    input_m = truth_m if input_ is None else _numeric(input_)
+    if pred.shape != truth_m.shape or pred.shape != input_m.shape:
         raise ValueError("All matrices must have the same dimensions")
-    if true_names is None and isinstance(true, core.RMatrix):
+    if true_names is None and isinstance(true, (core.RMatrix, core.CodedMatrix)):
         true_names = true.names
     if pred_names is not None and true_names is not None:
         lookup = {nm: q for q, nm in enumerate(pred_names)}
@@ -36,8 +40,8 @@ def error_calculator_comparison(predicted, true, input_=None, pred_names=None, t
             raise ValueError("Row and column names must match between matrices after ordering") from None
         pred = pred[np.ix_(order, order)]
     # R flattens column-major; the statistics below do not depend on the order
-    truth = core._as_numeric(true_v).ravel(order="F")
-    inputv = core._as_numeric(inp_v).ravel(order="F")
+    truth = truth_m.ravel(order="F")
+    inputv = input_m.ravel(order="F")
     predv = pred.ravel(order="F")
     missing = np.isnan(inputv)
     in_err = np.where(~missing, truth - predv, np.nan)
@@ -55,13 +59,12 @@ def error_calculator_comparison(predicted, true, input_=None, pred_names=None, t
 def make_folds(values: np.ndarray, folds: int, rng: np.random.Generator):
     """Holdout index sets of R/adaptive_sampling.R:2570-2598: `folds` disjoint draws of
     floor(#non-NA / (2 folds)) linear (column-major) indices; a drawn cell and its mirror leave
-    the pool."""
+    the pool.  `values`: stripped numeric matrix, NaN = NA."""
     n = values.shape[0]
-    pool = ~core._is_na(values)
+    pool = ~np.isnan(np.asarray(values, dtype=np.float64))
     num_elements = int(pool.sum())
     holdout_size = num_elements // (folds * 2)
     out = []
-    pool = pool.copy()
     for _ in range(folds):
         avail = np.flatnonzero(pool.ravel(order="F"))
         if avail.size < holdout_size:
@@ -75,16 +78,6 @@ def make_folds(values: np.ndarray, folds: int, rng: np.random.Generator):
     return out
 
 
-def _mask(values: np.ndarray, holdout: np.ndarray) -> np.ndarray:
-    n = values.shape[0]
-    m = values.astype(object, copy=True) if core._is_character(values) else values.astype(np.float64, copy=True)
-    r, c = holdout % n, holdout // n
-    na = None if core._is_character(values) else np.nan
-    m[r, c] = na
-    m[c, r] = na
-    return m
-
-
 def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]], mapping_max_iter: int,
                      relative_epsilon: float, folds: int = 20, preserve_order: bool = False,
                      rng: Optional[np.random.Generator] = None, precision: str = "f64"):
@@ -92,14 +85,15 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     in ONE batched launch.  param_sets: dicts with N (ndim), k0, cooling_rate, c_repulsion.
     Returns (list of result dicts, device_seconds, embeddings)."""
     rng = rng if rng is not None else _native.host_rng()
-    m = core._as_rmatrix(dissimilarity_matrix)
+    m = core.coded_matrix(dissimilarity_matrix)   # strings are parsed once, not once per fold
     if m is None:
         raise ValueError("dissimilarity_matrix must be a matrix")
     calls, owners, inputs = [], [], []
     for s_idx, ps in enumerate(param_sets):
         fold_sets = make_folds(m.values, folds, rng)
+        n_pts = m.values.shape[0]
         for h in fold_sets:
-            masked = core.RMatrix(_mask(m.values, h), m.names)
+            masked = m.masked(h % n_pts, h // n_pts)
             try:
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
