@@ -21,7 +21,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <numeric>
+#include <string>
 #include <vector>
 
 #include "../../include/topolow_relax.h"
@@ -88,6 +91,13 @@ struct GsDev {
   const int8_t* cm;      // n x n threshold codes (0, 1, -1)
   const double* gplus;   // n: degree + 1
   const int* ei; const int* ej; const double* et; const int8_t* ec;  // MAE edge list
+  // SPARSE kernels only: the measured pairs as a CSR table over rows i (entries j > i, ascending),
+  // copied into LDS at start so the round loop touches no global memory at all
+  const int* row_off;            // n + 1
+  const unsigned short* ecol;    // n_edges
+  const unsigned short* erow;    // n_edges
+  const real* etgt;              // n_edges (targets in the kernel's precision)
+  const int8_t* ecode;           // n_edges
   real* pos;             // n x dim row-major: in = initial positions, out = best positions
   real* best;            // n x dim scratch
   GsOut* out;
@@ -138,6 +148,50 @@ __device__ __forceinline__ void gs_pair_update(real* pi, real* pj, real target, 
   }
 }
 
+// fp32 variant: not bit-comparable with anything anyway, so the 2*DIM divisions per pair of the
+// reference's operation order collapse into two reciprocals (v_rcp_f32) and v_sqrt_f32.
+template <int DIM>
+__device__ __forceinline__ void gs_pair_update(float* pi, float* pj, float target, int code,
+                                               double gi, double gj, double k, double c_rep) {
+  float dx[DIM];
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    dx[d] = pj[d] - pi[d];
+    s = fmaf(dx[d], dx[d], s);
+  }
+  const float dist = __builtin_amdgcn_sqrtf(s);
+  const float inv = __builtin_amdgcn_rcpf(dist + 0.01f);
+  bool spring = false;
+  if (isfinite(target)) {
+    if (code == 0) spring = true;
+    else if (code == 1) spring = dist < target;
+    else spring = dist > target;
+  }
+  float ci, cj;
+  if (spring) {
+    const float factor = 2.0f * (float)k * (target - dist) * inv;
+    ci = factor * __builtin_amdgcn_rcpf(4.0f * (float)gi + (float)k);
+    cj = factor * __builtin_amdgcn_rcpf(4.0f * (float)gj + (float)k);
+  } else {
+    const float mag = 0.5f * (float)c_rep * inv * inv * inv;
+    ci = mag * __builtin_amdgcn_rcpf((float)gi);
+    cj = mag * __builtin_amdgcn_rcpf((float)gj);
+  }
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    pi[d] = fmaf(-dx[d], ci, pi[d]);
+    pj[d] = fmaf(dx[d], cj, pj[d]);
+  }
+}
+
+template <int DIM, typename real>
+__device__ __forceinline__ void gs_pair_dispatch(real* pi, real* pj, real target, int code, double gi,
+                                                 double gj, double k, double c_rep) {
+  if constexpr (sizeof(real) == 4) gs_pair_update<DIM>(pi, pj, target, code, gi, gj, k, c_rep);
+  else gs_pair_update<DIM, real>(pi, pj, target, code, gi, gj, k, c_rep);
+}
+
 // Block-wide sum of (double, u64) in a fixed order; result valid in every thread.
 __device__ inline void gs_block_sum(double& s, unsigned long long& c, double* sh_s,
                                     unsigned long long* sh_c) {
@@ -157,7 +211,9 @@ __device__ inline void gs_block_sum(double& s, unsigned long long& c, double* sh
   c = tc;
 }
 
-template <int DIM, typename real>
+//   SPARSE = true: targets come from the LDS-resident CSR table (sparse panels: antigenic data is
+//   > 90 % missing); false: from the dense n x n matrix in global memory.
+template <int DIM, typename real, bool SPARSE>
 __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __restrict__ problems) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
   const GsDev<real> P = problems[blockIdx.x];
@@ -172,17 +228,56 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
   off += ((size_t)(n + 1) * sizeof(int) + 15) & ~(size_t)15;
   uint32_t* keys = reinterpret_cast<uint32_t*>(gs_smem + off);
   off += ((size_t)n * sizeof(uint32_t) + 15) & ~(size_t)15;
+  double* lds_g = reinterpret_cast<double*>(gs_smem + off);   // degree + 1 of every point
+  off += ((size_t)n * sizeof(double) + 15) & ~(size_t)15;
   double* sh_s = reinterpret_cast<double*>(gs_smem + off);
   off += 16 * sizeof(double);
   unsigned long long* sh_c = reinterpret_cast<unsigned long long*>(gs_smem + off);
   off += 16 * sizeof(unsigned long long);
   int* sh_flag = reinterpret_cast<int*>(gs_smem + off);
+  off += 16;
+  // CSR table of the measured pairs (SPARSE only)
+  const int ne = SPARSE ? (int)P.n_edges : 0;
+  real* l_tgt = reinterpret_cast<real*>(gs_smem + off);
+  off += ((size_t)ne * sizeof(real) + 7) & ~(size_t)7;
+  int* l_off = reinterpret_cast<int*>(gs_smem + off);
+  off += ((size_t)(n + 1) * sizeof(int) + 7) & ~(size_t)7;
+  unsigned short* l_col = reinterpret_cast<unsigned short*>(gs_smem + off);
+  off += ((size_t)ne * 2 + 7) & ~(size_t)7;
+  unsigned short* l_row = reinterpret_cast<unsigned short*>(gs_smem + off);
+  off += ((size_t)ne * 2 + 7) & ~(size_t)7;
+  int8_t* l_code = reinterpret_cast<int8_t*>(gs_smem + off);
+  if constexpr (SPARSE) {
+    for (int q = tid; q < ne; q += nthr) {
+      l_tgt[q] = P.etgt[q]; l_col[q] = P.ecol[q]; l_row[q] = P.erow[q]; l_code[q] = P.ecode[q];
+    }
+    for (int q = tid; q <= n; q += nthr) l_off[q] = P.row_off[q];
+  }
+  // target and code of the pair (i < j): binary search of j in row i of the table, or the dense cell
+  auto lookup = [&](int i, int j, real& target, int& code) {
+    if constexpr (SPARSE) {
+      int lo = l_off[i], hi = l_off[i + 1];
+      target = (real)INFINITY;   // unmeasured (reference R/core.R:345)
+      code = 0;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = l_col[mid];
+        if (c == j) { target = (real)l_tgt[mid]; code = l_code[mid]; break; }
+        if (c < j) lo = mid + 1; else hi = mid;
+      }
+    } else {
+      const size_t cell = (size_t)i + (size_t)j * n;
+      target = P.tm[cell];
+      code = P.cm[cell];
+    }
+  };
 
   for (int q = tid; q < n * DIM; q += nthr) {
     const real v = P.pos[q];
     pos[q] = v;
     P.best[q] = v;  // reference :171: best_pos starts as the initial positions
   }
+  for (int q = tid; q < n; q += nthr) lds_g[q] = P.gplus[q];
   if (tid == 0) { perm[n] = n; sh_flag[0] = 0; sh_flag[1] = 0; }
 
   Controller ctl;
@@ -209,22 +304,56 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
     __syncthreads();
 
     // ---- m1 rounds of disjoint pairs ----
-    for (int r = 0; r < m1; ++r) {
-      int rr = r + r0; if (rr >= m1) rr -= m1;
-      for (int p = tid; p < half; p += nthr) {
-        int a, b;
-        gs_round_pair(m1, rr, p, &a, &b);
-        int i = perm[a], j = perm[b];
-        if (i < n && j < n) {
-          if (i > j) { const int t = i; i = j; j = t; }  // reference pairs have i<j
-          const size_t cell = (size_t)i + (size_t)j * n;
-          const real target = P.tm[cell];
-          const int code = P.cm[cell];
-          gs_pair_update<DIM, real>(pos + (size_t)i * DIM, pos + (size_t)j * DIM, target, code,
-                                    P.gplus[i], P.gplus[j], k, P.c_rep);
+    if (half <= nthr) {
+      // one pair per thread per round: the NEXT round's target word is requested before the
+      // current pair is relaxed, so the (random, L2-missing) target fetch overlaps the arithmetic
+      // and the barrier instead of heading every round
+      int ci = n, cj = n, ccode = 0;
+      real ctarget = 0;
+      auto fetch = [&](int r, int& fi, int& fj, real& ft, int& fc) {
+        int rr = r + r0; if (rr >= m1) rr -= m1;
+        fi = n; fj = n; ft = 0; fc = 0;
+        if (tid < half) {
+          int a, b;
+          gs_round_pair(m1, rr, tid, &a, &b);
+          int i = perm[a], j = perm[b];
+          if (i < n && j < n) {
+            if (i > j) { const int t = i; i = j; j = t; }  // reference pairs have i<j
+            lookup(i, j, ft, fc);
+            fi = i; fj = j;
+          }
         }
+      };
+      fetch(0, ci, cj, ctarget, ccode);
+      for (int r = 0; r < m1; ++r) {
+        int ni = n, nj = n, ncode = 0;
+        real ntarget = 0;
+        if (r + 1 < m1) fetch(r + 1, ni, nj, ntarget, ncode);
+        if (ci < n) {
+          gs_pair_dispatch<DIM, real>(pos + (size_t)ci * DIM, pos + (size_t)cj * DIM, ctarget, ccode,
+                                      lds_g[ci], lds_g[cj], k, P.c_rep);
+        }
+        ci = ni; cj = nj; ctarget = ntarget; ccode = ncode;
+        __syncthreads();
       }
-      __syncthreads();
+    } else {
+      for (int r = 0; r < m1; ++r) {
+        int rr = r + r0; if (rr >= m1) rr -= m1;
+        for (int p = tid; p < half; p += nthr) {
+          int a, b;
+          gs_round_pair(m1, rr, p, &a, &b);
+          int i = perm[a], j = perm[b];
+          if (i < n && j < n) {
+            if (i > j) { const int t = i; i = j; j = t; }  // reference pairs have i<j
+            real target;
+            int code;
+            lookup(i, j, target, code);
+            gs_pair_dispatch<DIM, real>(pos + (size_t)i * DIM, pos + (size_t)j * DIM, target, code,
+                                        lds_g[i], lds_g[j], k, P.c_rep);
+          }
+        }
+        __syncthreads();
+      }
     }
     iters_run = iter + 1;
     k *= (1.0 - P.cooling);  // reference :289
@@ -234,7 +363,7 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
       double s = 0.0;
       unsigned long long c = 0;
       for (long long e = tid; e < P.n_edges; e += nthr) {
-        const int a = P.ei[e], b = P.ej[e];
+        const int a = SPARSE ? (int)l_row[e] : P.ei[e], b = SPARSE ? (int)l_col[e] : P.ej[e];
         double q = 0.0;
         {
 #pragma clang fp contract(off)
@@ -245,8 +374,8 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
           }
         }
         const double rdist = sqrt(q);
-        const double t = P.et[e];
-        const int cd = P.ec[e];
+        const double t = SPARSE ? (double)l_tgt[e] : P.et[e];
+        const int cd = SPARSE ? (int)l_code[e] : (int)P.ec[e];
         if ((cd == 0) || (cd == 1 && rdist < t) || (cd == -1 && rdist > t)) {
           s += fabs(t - rdist);
           ++c;
@@ -310,13 +439,23 @@ struct GsResult {
   double final_mae, final_k;
 };
 
-inline size_t gs_lds_bytes(int n, int dim, size_t real_size) {
+inline size_t gs_lds_bytes(int n, int dim, size_t real_size, long long csr_edges = 0) {
   size_t off = ((size_t)n * dim * real_size + 15) & ~(size_t)15;
   off += ((size_t)(n + 1) * 4 + 15) & ~(size_t)15;
   off += ((size_t)n * 4 + 15) & ~(size_t)15;
+  off += ((size_t)n * 8 + 15) & ~(size_t)15;
   off += 16 * 8 + 16 * 8 + 16;
+  if (csr_edges > 0) {
+    off += ((size_t)csr_edges * real_size + 7) & ~(size_t)7;
+    off += ((size_t)(n + 1) * 4 + 7) & ~(size_t)7;
+    off += 2 * (((size_t)csr_edges * 2 + 7) & ~(size_t)7);
+    off += ((size_t)csr_edges + 15) & ~(size_t)15;
+  }
   return off;
 }
+
+// LDS budget under which the sparse (LDS-resident) table is used; two workgroups per CU still fit.
+constexpr size_t kGsSparseLdsBudget = 76 * 1024;
 
 struct GsHipError { int code; std::string msg; };
 #define GS_TRY(expr)                                                                      \
@@ -330,20 +469,52 @@ template <typename real>
 struct GsDeviceProblem {
   real* tm = nullptr; int8_t* cm = nullptr; double* gplus = nullptr;
   int* ei = nullptr; int* ej = nullptr; double* et = nullptr; int8_t* ec = nullptr;
+  int* row_off = nullptr; unsigned short* ecol = nullptr; unsigned short* erow = nullptr;
+  real* etgt = nullptr;
   real* pos = nullptr; real* best = nullptr;
   void release() {
     (void)hipFree(tm); (void)hipFree(cm); (void)hipFree(gplus); (void)hipFree(ei); (void)hipFree(ej);
-    (void)hipFree(et); (void)hipFree(ec); (void)hipFree(pos); (void)hipFree(best);
+    (void)hipFree(et); (void)hipFree(ec); (void)hipFree(row_off); (void)hipFree(ecol); (void)hipFree(erow);
+    (void)hipFree(etgt);
+    (void)hipFree(pos); (void)hipFree(best);
   }
 };
 
 template <int DIM, typename real>
-void gs_launch(const GsDev<real>* d_problems, int count, int threads, size_t lds, hipStream_t st) {
-  if (lds > 64 * 1024)
-    GS_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gs_embed_kernel<DIM, real>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((gs_embed_kernel<DIM, real>), dim3(count), dim3(threads), lds, st, d_problems);
-  GS_TRY(hipGetLastError());
+void gs_launch(const GsDev<real>* d_problems, int count, int threads, size_t lds, bool sparse,
+               hipStream_t st) {
+  auto go = [&](auto kern) {
+    if (lds > 64 * 1024)
+      GS_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(count), dim3(threads), lds, st, d_problems);
+    GS_TRY(hipGetLastError());
+  };
+  if (sparse) go(&gs_embed_kernel<DIM, real, true>);
+  else go(&gs_embed_kernel<DIM, real, false>);
+}
+
+// The measured upper-triangle cells of the dense inputs are exactly the caller's edge list (same
+// pairs, targets and codes)?  True for everything the reference's R driver builds (R/core.R:383-402
+// and :429-436 derive both from one matrix); required before the edge list may stand in for the
+// matrix in the LDS-resident table.
+inline bool gs_edges_match_matrix(const GsProblem& p) {
+  const int n = p.n;
+  long long measured = 0;
+  for (int j = 1; j < n; ++j)
+    for (int i = 0; i < j; ++i)
+      if (std::isfinite(p.D[(size_t)i + (size_t)j * n])) ++measured;
+  if (measured != p.n_edges) return false;
+  for (long long e = 0; e < p.n_edges; ++e) {
+    const int a = p.edge_i[e], b = p.edge_j[e];
+    if (a < 0 || b <= a || b >= n) return false;
+    const size_t cell = (size_t)a + (size_t)b * n;
+    if (!(p.D[cell] == p.edge_dist[e])) return false;
+    const int tc = p.T[cell], ec = p.edge_thresh[e];
+    const int tn = tc == 0 ? 0 : (tc == 1 ? 1 : -1), en = ec == 0 ? 0 : (ec == 1 ? 1 : -1);
+    if (tn != en) return false;
+  }
+  return true;
 }
 
 template <typename real>
@@ -363,12 +534,21 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
     const int dim = pbs[0].dim;
     size_t lds_max = 0;
     int n_max = 0;
+    // one kernel instance per launch: the LDS-resident table is used when EVERY problem of the
+    // batch qualifies (edge list == matrix, n < 65536, table within the LDS budget)
+    bool sparse = getenv("TOPOLOW_GS_DENSE") == nullptr;
+    for (int b = 0; b < count && sparse; ++b) {
+      const GsProblem& p = pbs[b];
+      sparse = p.n < 65536 && p.n_edges > 0 &&
+               gs_lds_bytes(p.n, dim, sizeof(real), p.n_edges) <= kGsSparseLdsBudget &&
+               gs_edges_match_matrix(p);
+    }
     GS_TRY(hipMalloc((void**)&d_out, sizeof(GsOut) * count));
     for (int b = 0; b < count; ++b) {
       const GsProblem& p = pbs[b];
       if (p.dim != dim) throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "batch must share ndim"};
       if (p.n < 2) throw GsHipError{TOPOLOW_ERR_TOO_FEW_POINTS, "Need at least 2 points for embedding"};
-      const size_t lds = gs_lds_bytes(p.n, dim, sizeof(real));
+      const size_t lds = gs_lds_bytes(p.n, dim, sizeof(real), sparse ? p.n_edges : 0);
       if (lds > 160 * 1024)
         throw GsHipError{TOPOLOW_ERR_UNSUPPORTED,
                          "problem too large for the single-workgroup GS kernel (LDS); use the slab schedule"};
@@ -411,8 +591,37 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
         GS_TRY(hipMemcpy(d.ec, ec.data(), ne, hipMemcpyHostToDevice));
       }
       GS_TRY(hipMemcpy(d.pos, pos.data(), nd * sizeof(real), hipMemcpyHostToDevice));
+      if (sparse) {
+        // CSR over rows (entries sorted by row, then column); the caller's list is column-major
+        std::vector<long long> order(ne);
+        std::iota(order.begin(), order.end(), 0ll);
+        std::sort(order.begin(), order.end(), [&](long long x, long long y) {
+          return p.edge_i[x] != p.edge_i[y] ? p.edge_i[x] < p.edge_i[y] : p.edge_j[x] < p.edge_j[y];
+        });
+        std::vector<int> roff(p.n + 1, 0);
+        std::vector<unsigned short> col(ne), row(ne);
+        std::vector<real> tgt(ne);
+        std::vector<int8_t> code(ne);
+        for (size_t q = 0; q < ne; ++q) {
+          const long long e = order[q];
+          row[q] = (unsigned short)p.edge_i[e]; col[q] = (unsigned short)p.edge_j[e];
+          tgt[q] = (real)p.edge_dist[e]; code[q] = ec[e];
+          roff[p.edge_i[e] + 1] += 1;
+        }
+        for (int i = 0; i < p.n; ++i) roff[i + 1] += roff[i];
+        GS_TRY(hipMalloc((void**)&d.row_off, (p.n + 1) * 4));
+        GS_TRY(hipMalloc((void**)&d.ecol, ne * 2));
+        GS_TRY(hipMalloc((void**)&d.erow, ne * 2));
+        GS_TRY(hipMemcpy(d.row_off, roff.data(), (p.n + 1) * 4, hipMemcpyHostToDevice));
+        GS_TRY(hipMemcpy(d.ecol, col.data(), ne * 2, hipMemcpyHostToDevice));
+        GS_TRY(hipMemcpy(d.erow, row.data(), ne * 2, hipMemcpyHostToDevice));
+        GS_TRY(hipMalloc((void**)&d.etgt, ne * sizeof(real)));
+        GS_TRY(hipMemcpy(d.etgt, tgt.data(), ne * sizeof(real), hipMemcpyHostToDevice));
+        GS_TRY(hipMemcpy(d.ec, code.data(), ne, hipMemcpyHostToDevice));       // reuse: sorted codes
+      }
       GsDev<real>& k = h[b];
       k.tm = d.tm; k.cm = d.cm; k.gplus = d.gplus; k.ei = d.ei; k.ej = d.ej; k.et = d.et; k.ec = d.ec;
+      k.row_off = d.row_off; k.ecol = d.ecol; k.erow = d.erow; k.etgt = d.etgt; k.ecode = d.ec;
       k.pos = d.pos; k.best = d.best; k.out = d_out + b; k.n_edges = p.n_edges;
       k.k0 = p.k0; k.cooling = p.cooling; k.c_rep = p.c_rep; k.eps = p.eps; k.seed = p.seed;
       k.n = p.n; k.n_iter = p.n_iter; k.check_freq = p.check_freq; k.window = p.window;
@@ -426,7 +635,7 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
     GS_TRY(hipEventCreate(&e1));
     GS_TRY(hipEventRecord(e0, 0));
     switch (dim) {
-#define GS_CASE(D) case D: gs_launch<D, real>(d_problems, count, threads, lds_max, 0); break;
+#define GS_CASE(D) case D: gs_launch<D, real>(d_problems, count, threads, lds_max, sparse, 0); break;
       GS_CASE(1) GS_CASE(2) GS_CASE(3) GS_CASE(4) GS_CASE(5) GS_CASE(6) GS_CASE(7) GS_CASE(8)
       GS_CASE(9) GS_CASE(10)
 #undef GS_CASE
