@@ -178,3 +178,25 @@ def test_create_topolow_map_deprecation_and_signature():
     assert sig2.parameters["convergence_check_freq"].default == 3
     assert sig2.parameters["mapping_max_iter"].default == 1000
     assert sig2.parameters["relative_epsilon"].default == 1e-4
+
+
+def test_r_compatible_seed_reproduces_r_runif_and_initial_positions():
+    """set.seed(s); runif() of R's default generator.  The expected
+    numbers are the well-known heads of R's streams (e.g. `set.seed(123); runif(3)`)."""
+    from topolow_amd.r_rng import RUnif
+    assert np.allclose(RUnif(123).runif(5), [0.2875775, 0.7883051, 0.4089769, 0.8830174, 0.9404673], atol=5e-8)
+    assert np.allclose(RUnif(42).runif(3), [0.9148060, 0.9370754, 0.2861395], atol=5e-8)
+    assert np.allclose(RUnif(1).runif(3), [0.2655087, 0.3721239, 0.5728534], atol=5e-8)
+    # initial positions of R/core.R:407-415 after set.seed(123): cumsum of runif((n-1)*ndim, 0, 2*max/n),
+    # filled column by column
+    D = np.array([[0, 2, 3], [2, 0, 4], [3, 4, 0]], float)
+    call = core.prepare_layout_call(D, 2, 5, 1.0, 0.1, 0.1, 1e-4, 5, None, False, 3, True, RUnif(123))
+    u = np.array([0.2875775201246142, 0.7883051354438066, 0.4089769218116999, 0.8830174040049314])
+    step = 2 * 4.0 / 3
+    want = np.array([[0, 0], [u[0] * step, u[2] * step], [(u[0] + u[1]) * step, (u[2] + u[3]) * step]])
+    assert np.allclose(call.initial_positions, want, atol=1e-7)
+    import topolow_amd
+    topolow_amd.set_seed(123)
+    from topolow_amd import _native
+    assert abs(_native.host_rng().unif_rand() - 0.2875775201246142) < 1e-12
+    topolow_amd.set_seed(None)

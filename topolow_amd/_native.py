@@ -76,11 +76,19 @@ _PRECISIONS = {"auto": PRECISION_AUTO, "f32": PRECISION_F32, "f64": PRECISION_F6
 
 
 def set_seed(seed: Optional[int]) -> None:
-    """Seed both the random-walk initial positions and the native pair/slab order stream
-    (the reference seeds only the former from R's RNG; its shuffle uses random_device)."""
+    """The Python spelling of R's `set.seed(seed)`: the random-walk initial positions are then drawn
+    from R's own Mersenne-Twister stream (topolow_amd/r_rng.py), i.e. they equal what the reference
+    computes after `set.seed(seed)` (R/core.R:412); the native pair/slab order seed is the next draw
+    of the same stream, so the whole run is reproducible (the reference's shuffle is not: it is
+    seeded from std::random_device, src/optimization.cpp:153-154).  set_seed(None) returns to
+    OS entropy."""
     global _host_rng
-    options["seed"] = seed
-    _host_rng = np.random.default_rng(seed)
+    options["seed"] = None
+    if seed is None:
+        _host_rng = np.random.default_rng()
+    else:
+        from .r_rng import RUnif
+        _host_rng = RUnif(int(seed))
 
 
 def host_rng() -> np.random.Generator:

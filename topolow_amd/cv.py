@@ -85,6 +85,8 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     in ONE batched launch.  param_sets: dicts with N (ndim), k0, cooling_rate, c_repulsion.
     Returns (list of result dicts, device_seconds, embeddings)."""
     rng = rng if rng is not None else _native.host_rng()
+    if not hasattr(rng, "choice"):   # R-stream generator: fold sampling uses a NumPy stream seeded from it
+        rng = np.random.default_rng(rng.integers(0, 2 ** 53))
     m = core.coded_matrix(dissimilarity_matrix)   # strings are parsed once, not once per fold
     if m is None:
         raise ValueError("dissimilarity_matrix must be a matrix")
