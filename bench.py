@@ -117,6 +117,8 @@ def run_single(args):
     # command (profiles/: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, per launch); null if absent.
     traffic = None
     try:
+        if n != 10000:
+            raise ValueError("the committed PMC run is for the config-3 size only")
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
             for name, vals in json.load(fh).items():
                 if "slab_stage_kernel<5, float" in name and "hbm_traffic_bytes_per_launch" in vals:

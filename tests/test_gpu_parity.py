@@ -352,3 +352,51 @@ def test_full_size_properties():
     scale = np.abs(pos - call.initial_positions).max()
     assert np.abs(got - pos).max() <= 3e-4 * scale
     s.close()
+
+
+# ----------------------------------------------------------------------------------------
+# edge cases of the slab path (the reference's edge-case tests, forced onto the large-N kernels)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 3, 5, 9, 64, 65])
+def test_slab_tiny_problems_match_model(n):
+    call, _ = _random_problem(n, 2, 0.2 if n > 4 else 0.0, seed=50 + n, n_iter=4)
+    s = _native.Session(n, 2, precision="f64")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    s.set_positions(call.initial_positions)
+    s.begin(4, call.k0, call.cooling_rate, call.c_repulsion, 1e-12, 1000, 2, 5, 0)
+    s.run()
+    got = s.get_positions()
+    import dataclasses
+    want, _k = _model_run(dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call)), 5, 0, 4, "f64")
+    assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    s.close()
+
+
+def test_slab_nonfinite_guard_and_messages():
+    call, _ = _random_problem(600, 3, 0.5, seed=8, n_iter=40)
+    bad = call.initial_positions.copy()
+    bad[17, 1] = np.inf
+    args = list(layout_call_args(call)); args[0] = bad
+    with pytest.raises(_native.NativeError, match=r"Numerical instability at iteration 10\. Reduce k0 or c_repulsion\.") as ei:
+        _native.optimize_layout_exact_arrays(*args, seed=1, schedule="slab")
+    assert ei.value.code == _native.ERR_NONFINITE
+    with pytest.raises(_native.NativeError) as ei:
+        _native.optimize_layout_exact_arrays(np.zeros((4, 11)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
+                                             [0] * 4, [], [], [], [], 5, 1.0, 0.1, 0.1, 1e-4, 5, 3, seed=1,
+                                             schedule="slab")
+    assert ei.value.code == _native.ERR_UNSUPPORTED
+
+
+def test_slab_no_measurements_only_repulsion():
+    """All pairs unmeasured: MAE is 0 by definition (reference :296), points only repel."""
+    n = 300
+    rng = np.random.default_rng(0)
+    pos0 = rng.normal(size=(n, 2))
+    D = np.full((n, n), np.inf); T = np.zeros((n, n), np.int32)
+    got = _native.optimize_layout_exact_arrays(pos0, D, T, np.zeros(n, np.int32), [], [], [], [], 9, 1.0, 0.1, 0.05,
+                                               1e-4, 2, 3, seed=3, schedule="slab")
+    ref = orc.optimize_layout_exact(pos0, D, T, np.zeros(n, np.int32), [], [], [], [], 9, 1.0, 0.1, 0.05, 1e-4, 2, 3,
+                                    seed=3)
+    assert got.final_mae == ref.final_mae == 0.0 and got.converged == ref.converged
+    assert got.iterations == ref.iterations == 3       # first check improves (0 < DBL_MAX), next two plateau
