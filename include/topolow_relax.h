@@ -218,6 +218,11 @@ int64_t topolow_session_bytes_per_iteration(const topolow_session* s);
  * caller's, e.g. torch.distributed/RCCL).  d_pos_* are device pointers to n x ndim
  * row-major positions in the session's precision.
  * ------------------------------------------------------------------------------------- */
+/* Iteration body of the session: TOPOLOW_SCHEDULE_SLAB (default) or TOPOLOW_SCHEDULE_GS = exact
+ * Gauss-Seidel across workgroups in tile-tournament order (whole-problem sessions only). */
+int topolow_session_set_schedule(topolow_session* s, int32_t schedule);
+/* Visiting order of the tile Gauss-Seidel schedule for iteration `iter` (as topolow_gs_pair_order). */
+int64_t topolow_tilegs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_t* pairs_out);
 /* Rows a caller-owned position buffer must hold: roundup4(n).  Rows [n, roundup4(n)) are the
  * phantom points of the padding columns and must be (1e18, 0, ..., 0) (1e150 in f64 sessions) in
  * BOTH ping-pong buffers; stages never write them. */

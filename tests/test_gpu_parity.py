@@ -400,3 +400,46 @@ def test_slab_no_measurements_only_repulsion():
                                     seed=3)
     assert got.final_mae == ref.final_mae == 0.0 and got.converged == ref.converged
     assert got.iterations == ref.iterations == 3       # first check improves (0 < DBL_MAX), next two plateau
+
+
+# ----------------------------------------------------------------------------------------
+# exact Gauss-Seidel across workgroups (tile schedule): replayed pair for pair by the oracle
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,missing,thr", [(64, 2, 0.3, 0.0), (65, 3, 0.5, 0.2), (130, 5, 0.6, 0.1),
+                                               (200, 2, 0.8, 0.0), (777, 5, 0.7, 0.15), (1500, 3, 0.9, 0.0)])
+def test_tile_gs_f64_matches_oracle_same_order(n, dim, missing, thr):
+    import dataclasses
+    call, _ = _random_problem(n, dim, missing, seed=300 + n, thresholds=thr, n_iter=7, check_freq=2)
+    rounded = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call),
+                                  edge_dist=np.array([_native.decode_target(_native.encode_target(v, 0))[0]
+                                                      for v in call.edge_dist]))
+    seed = 77
+    s = _native.Session(n, dim, precision="f64")
+    s.set_schedule("gs")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(rounded.edge_i, rounded.edge_j, rounded.edge_dist, rounded.edge_thresh)
+    s.set_positions(call.initial_positions)
+    s.begin(7, call.k0, call.cooling_rate, call.c_repulsion, 1e-4, 5, 2, seed, 0)
+    s.run()
+    got = s.finish()
+    s.close()
+
+    def order_fn(it, arr):
+        arr[:] = _native.tilegs_pair_order(n, seed, it)
+    ref = orc.optimize_layout_exact(*layout_call_args(rounded), order_mode=orc.ORDER_SUPPLIED, order_fn=order_fn)
+    assert np.abs(got.positions - ref.positions).max() <= 1e-11
+    assert got.iterations == ref.iterations and got.converged == ref.converged
+    assert got.final_mae == pytest.approx(ref.final_mae, rel=1e-11)
+
+
+def test_tile_gs_through_the_call_boundary_and_statistics():
+    """schedule="gs" beyond the one-workgroup limit takes the tile schedule; its error level is the
+    reference schedule's."""
+    n, dim = 2500, 5
+    call, _ = _random_problem(n, dim, 0.7, seed=2500, n_iter=400, k0=14.76, cool=0.0364, c_rep=0.00294)
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1, schedule="gs")
+    assert got.info["schedule"] == "gs" and got.info["precision"] == "f64" and got.converged
+    slab = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1, schedule="slab")
+    assert abs(got.final_mae - slab.final_mae) <= 0.08 * got.final_mae
+    sm, cnt = orc.edge_error(got.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert got.final_mae == pytest.approx(sm / cnt, rel=1e-10)

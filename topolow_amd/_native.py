@@ -165,6 +165,10 @@ def load() -> C.CDLL:
     lib.topolow_session_set_stream.argtypes = [vp, vp, C.c_int32]
     lib.topolow_session_stream.restype = vp
     lib.topolow_session_stream.argtypes = [vp]
+    lib.topolow_session_set_schedule.restype = C.c_int
+    lib.topolow_session_set_schedule.argtypes = [vp, C.c_int32]
+    lib.topolow_tilegs_pair_order.restype = C.c_int64
+    lib.topolow_tilegs_pair_order.argtypes = [C.c_int32, C.c_uint64, C.c_int32, ip]
     lib.topolow_session_position_rows.restype = C.c_int32
     lib.topolow_session_position_rows.argtypes = [vp]
     lib.topolow_session_uses_dense_mae.restype = C.c_int32
@@ -375,6 +379,14 @@ def gs_pair_order(n: int, seed: int, it: int) -> np.ndarray:
     return buf
 
 
+def tilegs_pair_order(n: int, seed: int, it: int) -> np.ndarray:
+    lib = load()
+    buf = np.zeros((n * (n - 1) // 2, 2), dtype=np.int32)
+    cnt = lib.topolow_tilegs_pair_order(int(n), int(seed), int(it), _ip(buf))
+    assert cnt == buf.shape[0], (cnt, buf.shape)
+    return buf
+
+
 def encode_target(d: float, code: int) -> int:
     return int(load().topolow_encode_target(float(d), int(code)))
 
@@ -512,6 +524,11 @@ class Session:
         while self.enqueue(chunk) > 0:
             pass
         return self.sync()
+
+    def set_schedule(self, schedule: str):
+        rc = self.lib.topolow_session_set_schedule(self._h, _SCHEDULES[schedule])
+        if rc != OK:
+            raise NativeError(rc, "schedule not available for this session")
 
     def set_profiling(self, enable: bool):
         self.lib.topolow_session_set_profiling(self._h, int(bool(enable)))

@@ -23,6 +23,7 @@
 #include "relax_common.h"
 #include "relax_kernels.h"
 #include "relax_gs.h"
+#include "relax_tilegs.h"
 
 using namespace topolow;
 
@@ -110,6 +111,8 @@ struct topolow_session {
   DevBuf<float> gplus;
   DevBuf<unsigned char> rowflags;
   bool any_threshold = true;   // does any row of the block hold a ">" / "<" target?
+  int schedule = TOPOLOW_SCHEDULE_SLAB;   // SLAB, or GS = exact tile Gauss-Seidel (relax_tilegs.h)
+  DevBuf<int> bperm;
   DevBuf<unsigned char> pos[2];
   DevBuf<unsigned char> best;
   DevBuf<int> ei, ej;
@@ -403,6 +406,46 @@ void poll_checks(topolow_session* s, size_t keep_in_flight) {
     s->pending.pop_front();
     if (s->mailbox->stopped) s->host_seen_stop = true;
   }
+}
+
+// ---- exact tile Gauss-Seidel iteration (relax_tilegs.h): in place on `pos` -------------------
+template <int DIM>
+void launch_tilegs_iteration(topolow_session* s, void* pos, int iter, double k) {
+  const int nb = (s->n + kTile - 1) / kTile;
+  if ((int)s->bperm.n < nb) s->bperm.alloc(nb);
+  hipLaunchKernelGGL(tilegs_perm_kernel, dim3(1), dim3(256), 0, s->stream, s->seed, iter, nb, s->bperm.p,
+                     s->state.p);
+  const int M = nb + (nb & 1), m1 = M - 1;
+  for (int r = 0; r < m1 && nb >= 2; ++r) {
+    if (s->precision == TOPOLOW_PRECISION_F64)
+      hipLaunchKernelGGL((tilegs_pair_kernel<DIM, double>), dim3(M / 2), dim3(kTile), 0, s->stream, s->enc.p,
+                         s->ld, s->n, (double*)pos, s->gplus.p, s->bperm.p, nb, r, s->state.p, s->seed, iter, k,
+                         s->c_rep);
+    else
+      hipLaunchKernelGGL((tilegs_pair_kernel<DIM, float>), dim3(M / 2), dim3(kTile), 0, s->stream, s->enc.p,
+                         s->ld, s->n, (float*)pos, s->gplus.p, s->bperm.p, nb, r, s->state.p, s->seed, iter, k,
+                         s->c_rep);
+    s->stage_launches += 1;
+  }
+  if (s->precision == TOPOLOW_PRECISION_F64)
+    hipLaunchKernelGGL((tilegs_intra_kernel<DIM, double>), dim3(nb), dim3(kTile), 0, s->stream, s->enc.p, s->ld,
+                       s->n, (double*)pos, s->gplus.p, s->state.p, s->seed, iter, k, s->c_rep);
+  else
+    hipLaunchKernelGGL((tilegs_intra_kernel<DIM, float>), dim3(nb), dim3(kTile), 0, s->stream, s->enc.p, s->ld,
+                       s->n, (float*)pos, s->gplus.p, s->state.p, s->seed, iter, k, s->c_rep);
+  s->stage_launches += 1;
+  HIP_TRY(hipGetLastError());
+}
+
+void launch_tilegs_finite(topolow_session* s, const void* pos, int iter1) {
+  const long long nv = (long long)s->n * s->dim;
+  if (s->precision == TOPOLOW_PRECISION_F64)
+    hipLaunchKernelGGL((tilegs_finite_kernel<double>), dim3(64), dim3(256), 0, s->stream, (const double*)pos, nv,
+                       s->state.p, iter1);
+  else
+    hipLaunchKernelGGL((tilegs_finite_kernel<float>), dim3(64), dim3(256), 0, s->stream, (const float*)pos, nv,
+                       s->state.p, iter1);
+  HIP_TRY(hipGetLastError());
 }
 
 template <typename F>
@@ -758,13 +801,17 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
     int done = 0;
     while (done < max_iters && s->iters_enqueued < s->n_iter && !s->host_seen_stop) {
       const int iter = s->iters_enqueued;
-      const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_for_k(s->k_host);
-      const SlabGeom g = slab_geom(s->n, stages);
-      for (int slot = 0; slot < g.n_stages; ++slot) {
-        const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
-        TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[s->cur].p, s->pos[s->cur ^ 1].p,
-                        s->state.p, rg, iter + 1, s->k_host);
-        s->cur ^= 1;
+      if (s->schedule == TOPOLOW_SCHEDULE_GS) {
+        TL_DISPATCH_DIM(s->dim, launch_tilegs_iteration, s, s->pos[s->cur].p, iter, s->k_host);
+      } else {
+        const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_for_k(s->k_host);
+        const SlabGeom g = slab_geom(s->n, stages);
+        for (int slot = 0; slot < g.n_stages; ++slot) {
+          const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
+          TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[s->cur].p, s->pos[s->cur ^ 1].p,
+                          s->state.p, rg, iter + 1, s->k_host);
+          s->cur ^= 1;
+        }
       }
       s->iters_enqueued = iter + 1;
       s->k_host *= (1.0 - s->cooling);  // reference :289
@@ -780,6 +827,10 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         s->pending.push_back(e);
         poll_checks(s, 3);
       }
+      // the slab kernels flag non-finite results themselves; the in-place schedule is inspected at
+      // the reference's cadence (:359-361), after that iteration's check
+      if (s->schedule == TOPOLOW_SCHEDULE_GS && (iter + 1) % 10 == 0)
+        launch_tilegs_finite(s, s->pos[s->cur].p, iter + 1);
     }
     if (enqueued) *enqueued = done;
   });
@@ -871,6 +922,18 @@ int topolow_session_set_stream(topolow_session* s, void* hip_stream, int32_t ext
 }
 
 void* topolow_session_stream(topolow_session* s) { return s ? (void*)s->stream : nullptr; }
+
+int topolow_session_set_schedule(topolow_session* s, int32_t schedule) {
+  if (!s || (schedule != TOPOLOW_SCHEDULE_SLAB && schedule != TOPOLOW_SCHEDULE_GS))
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (s->row_begin != 0 || s->row_end != s->n) return TOPOLOW_ERR_UNSUPPORTED;  // tile GS: whole problem
+  s->schedule = schedule;
+  return TOPOLOW_OK;
+}
+
+int64_t topolow_tilegs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_t* pairs_out) {
+  return tilegs_pair_order(n, seed, iter, pairs_out);
+}
 
 int32_t topolow_session_position_rows(const topolow_session* s) { return s ? s->pos_rows() : 0; }
 
@@ -1026,7 +1089,11 @@ int topolow_optimize_layout_exact(
   if (schedule == TOPOLOW_SCHEDULE_AUTO)
     schedule = n <= gs_max_n ? TOPOLOW_SCHEDULE_GS : TOPOLOW_SCHEDULE_SLAB;
 
-  if (schedule == TOPOLOW_SCHEDULE_GS) {
+  // exact GS: one workgroup while the problem fits its LDS, the tile schedule beyond that
+  const bool gs_fits_lds =
+      gs_lds_bytes(n, ndim, (opt.precision == TOPOLOW_PRECISION_F32) ? 4 : 8) <= 150 * 1024 && n <= 2048;
+  const bool tile_gs = schedule == TOPOLOW_SCHEDULE_GS && !gs_fits_lds;
+  if (schedule == TOPOLOW_SCHEDULE_GS && !tile_gs) {
     int precision = opt.precision == TOPOLOW_PRECISION_AUTO ? TOPOLOW_PRECISION_F64 : opt.precision;
     GsProblem pb;
     pb.initial_positions = initial_positions; pb.n = n; pb.dim = ndim;
@@ -1061,15 +1128,20 @@ int topolow_optimize_layout_exact(
     return TOPOLOW_OK;
   }
 
-  // ---- slab schedule ----
-  const int precision =
-      opt.precision == TOPOLOW_PRECISION_AUTO ? TOPOLOW_PRECISION_F32 : opt.precision;
+  // ---- slab schedule, or exact tile Gauss-Seidel (same session, different iteration body) ----
+  const int precision = opt.precision == TOPOLOW_PRECISION_AUTO
+                            ? (tile_gs ? TOPOLOW_PRECISION_F64 : TOPOLOW_PRECISION_F32)
+                            : opt.precision;
   topolow_session* s = nullptr;
   int rc = topolow_session_create(&s, n, ndim, 0, n, precision, opt.device, errbuf, errlen);
   if (rc != TOPOLOW_OK) return rc;
   double t_dev0 = 0.0, t_dev1 = 0.0;
   int iters_run = 0, stopped = 0;
   do {
+    if (tile_gs) {
+      rc = topolow_session_set_schedule(s, TOPOLOW_SCHEDULE_GS);
+      if (rc) break;
+    }
     rc = topolow_session_load_dense(s, dissimilarity_matrix, threshold_matrix, degrees, errbuf, errlen);
     if (rc) break;
     rc = topolow_session_set_edges(s, edge_i, edge_j, edge_dist, edge_thresh, n_edges, errbuf, errlen);
@@ -1096,7 +1168,7 @@ int topolow_optimize_layout_exact(
   } while (0);
   if (rc == TOPOLOW_OK && stats) {
     std::memset(stats, 0, sizeof *stats);
-    stats->schedule_used = TOPOLOW_SCHEDULE_SLAB;
+    stats->schedule_used = tile_gs ? TOPOLOW_SCHEDULE_GS : TOPOLOW_SCHEDULE_SLAB;
     stats->precision_used = precision;
     stats->iterations_run = iters_run;
     stats->n_checks = s->mailbox->n_checks;
