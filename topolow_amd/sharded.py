@@ -76,14 +76,16 @@ class Collectives:
         """In-place all-gather: rank r contributes rows [r*per, (r+1)*per) of `full`."""
         if self.world == 1:
             return
-        import torch
-        mine = full[rank * per:(rank + 1) * per]
+        # the buffer may hold extra padding rows (roundup4(n)); only the world*per leading rows take
+        # part in the collective
+        out = full[: per * self.world]
+        mine = out[rank * per:(rank + 1) * per]
         if full.is_cuda and self.backend == "gloo":
-            host = full.cpu()
+            host = out.cpu()
             self.dist.all_gather_into_tensor(host, host[rank * per:(rank + 1) * per].clone())
-            full.copy_(host)
+            out.copy_(host)
         else:
-            self.dist.all_gather_into_tensor(full, mine.clone() if self.backend == "gloo" else mine)
+            self.dist.all_gather_into_tensor(out, mine.clone() if self.backend == "gloo" else mine)
 
     def all_reduce_sum(self, values: List[float]) -> List[float]:
         if self.world == 1:
