@@ -154,6 +154,9 @@ def run_single(args):
                      "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                        "separate passes, FETCH_SIZE x2 on gfx950)" if traffic else None,
                      "kernel": "slab_stage_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
+                     "timing": "HIP events on the session stream around every stage launch, in a second "
+                               "pass of the same K iterations (inside the timed pass the events themselves "
+                               "cost ~19% throughput); rocprofv3 kernel-trace mean: profiles/r01_kernel_stats.csv",
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "check_us": (check_ms * 1e3 / checks) if checks else None},
         "final_mae": res.final_mae,
