@@ -240,36 +240,46 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
   const int ne = SPARSE ? (int)P.n_edges : 0;
   real* l_tgt = reinterpret_cast<real*>(gs_smem + off);
   off += ((size_t)ne * sizeof(real) + 7) & ~(size_t)7;
-  int* l_off = reinterpret_cast<int*>(gs_smem + off);
-  off += ((size_t)(n + 1) * sizeof(int) + 7) & ~(size_t)7;
+  // per-iteration round schedule of the measured pairs: b_start[r] .. b_start[r+1] index the
+  // (slot, edge) entries of the pairs that meet in round r; rt[] are three rotating per-round
+  // slot -> edge tables (read this round / filled for the next / being cleared)
+  int* b_start = reinterpret_cast<int*>(gs_smem + off);
+  off += ((size_t)(n + 2) * sizeof(int) + 7) & ~(size_t)7;
+  int* b_cur = reinterpret_cast<int*>(gs_smem + off);
+  off += ((size_t)(n + 2) * sizeof(int) + 7) & ~(size_t)7;
   unsigned short* l_col = reinterpret_cast<unsigned short*>(gs_smem + off);
   off += ((size_t)ne * 2 + 7) & ~(size_t)7;
   unsigned short* l_row = reinterpret_cast<unsigned short*>(gs_smem + off);
   off += ((size_t)ne * 2 + 7) & ~(size_t)7;
+  unsigned short* b_slot = reinterpret_cast<unsigned short*>(gs_smem + off);
+  off += ((size_t)ne * 2 + 7) & ~(size_t)7;
+  unsigned short* b_edge = reinterpret_cast<unsigned short*>(gs_smem + off);
+  off += ((size_t)ne * 2 + 7) & ~(size_t)7;
+  unsigned short* rt = reinterpret_cast<unsigned short*>(gs_smem + off);   // [3][half]
+  off += ((size_t)3 * half * 2 + 7) & ~(size_t)7;
   int8_t* l_code = reinterpret_cast<int8_t*>(gs_smem + off);
   if constexpr (SPARSE) {
     for (int q = tid; q < ne; q += nthr) {
       l_tgt[q] = P.etgt[q]; l_col[q] = P.ecol[q]; l_row[q] = P.erow[q]; l_code[q] = P.ecode[q];
     }
-    for (int q = tid; q <= n; q += nthr) l_off[q] = P.row_off[q];
   }
-  // target and code of the pair (i < j): binary search of j in row i of the table, or the dense cell
-  auto lookup = [&](int i, int j, real& target, int& code) {
-    if constexpr (SPARSE) {
-      int lo = l_off[i], hi = l_off[i + 1];
-      target = (real)INFINITY;   // unmeasured (reference R/core.R:345)
-      code = 0;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const int c = l_col[mid];
-        if (c == j) { target = (real)l_tgt[mid]; code = l_code[mid]; break; }
-        if (c < j) lo = mid + 1; else hi = mid;
-      }
-    } else {
-      const size_t cell = (size_t)i + (size_t)j * n;
-      target = P.tm[cell];
-      code = P.cm[cell];
+  // round (in execution order) and slot in which the players a, b of a measured pair meet
+  auto meet = [&](int a, int b, int r0, int& r, int& p) {
+    int rr;
+    if (a == m1) { rr = b; p = 0; }
+    else if (b == m1) { rr = a; p = 0; }
+    else {
+      rr = (int)(((long long)(a + b) * ((m1 + 1) / 2)) % m1);
+      p = a - rr; if (p < 0) p += m1;
+      if (p >= half) { p = b - rr; if (p < 0) p += m1; }
     }
+    r = rr - r0; if (r < 0) r += m1;
+  };
+  // dense path: target and code of the pair (i < j) from the n x n matrix
+  auto lookup = [&](int i, int j, real& target, int& code) {
+    const size_t cell = (size_t)i + (size_t)j * n;
+    target = P.tm[cell];
+    code = P.cm[cell];
   };
 
   for (int q = tid; q < n * DIM; q += nthr) {
@@ -303,6 +313,60 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
     const int r0 = gs_round0(P.seed, iter, m1);
     __syncthreads();
 
+    if constexpr (SPARSE) {
+      // ---- bucket the measured pairs by the round in which they meet (host guarantees half <= nthr)
+      int* pinv = reinterpret_cast<int*>(keys);   // keys[] is free again: player index of every point
+      for (int a = tid; a < n; a += nthr) pinv[perm[a]] = a;
+      for (int q = tid; q <= m1 + 1; q += nthr) b_start[q] = 0;
+      for (int q = tid; q < 3 * half; q += nthr) rt[q] = 0;
+      __syncthreads();
+      for (int e = tid; e < ne; e += nthr) {
+        int r, p;
+        meet(pinv[l_row[e]], pinv[l_col[e]], r0, r, p);
+        atomicAdd(&b_start[r + 1], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int run = 0;
+        for (int r = 0; r <= m1; ++r) { run += b_start[r]; b_start[r] = run; b_cur[r] = run; }
+      }
+      __syncthreads();
+      for (int e = tid; e < ne; e += nthr) {
+        int r, p;
+        meet(pinv[l_row[e]], pinv[l_col[e]], r0, r, p);
+        const int at = atomicAdd(&b_cur[r], 1);
+        b_slot[at] = (unsigned short)p;
+        b_edge[at] = (unsigned short)e;
+      }
+      __syncthreads();
+      for (int q = b_start[0] + tid; q < b_start[1]; q += nthr) rt[b_slot[q]] = (unsigned short)(b_edge[q] + 1);
+      __syncthreads();
+      // ---- m1 rounds of disjoint pairs; one barrier per round ----
+      for (int r = 0; r < m1; ++r) {
+        int rr = r + r0; if (rr >= m1) rr -= m1;
+        unsigned short* rt_now = rt + (r % 3) * half;
+        unsigned short* rt_next = rt + ((r + 1) % 3) * half;
+        unsigned short* rt_clear = rt + ((r + 2) % 3) * half;
+        const int mine = tid < half ? rt_now[tid] : 0;
+        if (r + 1 < m1)
+          for (int q = b_start[r + 1] + tid; q < b_start[r + 2]; q += nthr)
+            rt_next[b_slot[q]] = (unsigned short)(b_edge[q] + 1);
+        if (tid < half) {
+          rt_clear[tid] = 0;
+          int a, b;
+          gs_round_pair(m1, rr, tid, &a, &b);
+          int i = perm[a], j = perm[b];
+          if (i < n && j < n) {
+            if (i > j) { const int t = i; i = j; j = t; }  // reference pairs have i<j
+            const real target = mine ? l_tgt[mine - 1] : (real)INFINITY;   // unmeasured: R/core.R:345
+            const int code = mine ? (int)l_code[mine - 1] : 0;
+            gs_pair_dispatch<DIM, real>(pos + (size_t)i * DIM, pos + (size_t)j * DIM, target, code, lds_g[i],
+                                        lds_g[j], k, P.c_rep);
+          }
+        }
+        __syncthreads();
+      }
+    } else
     // ---- m1 rounds of disjoint pairs ----
     if (half <= nthr) {
       // one pair per thread per round: the NEXT round's target word is requested before the
@@ -446,16 +510,18 @@ inline size_t gs_lds_bytes(int n, int dim, size_t real_size, long long csr_edges
   off += ((size_t)n * 8 + 15) & ~(size_t)15;
   off += 16 * 8 + 16 * 8 + 16;
   if (csr_edges > 0) {
+    const size_t half = (size_t)(n + (n & 1)) / 2;
     off += ((size_t)csr_edges * real_size + 7) & ~(size_t)7;
-    off += ((size_t)(n + 1) * 4 + 7) & ~(size_t)7;
-    off += 2 * (((size_t)csr_edges * 2 + 7) & ~(size_t)7);
+    off += 2 * (((size_t)(n + 2) * 4 + 7) & ~(size_t)7);
+    off += 4 * (((size_t)csr_edges * 2 + 7) & ~(size_t)7);
+    off += ((size_t)3 * half * 2 + 7) & ~(size_t)7;
     off += ((size_t)csr_edges + 15) & ~(size_t)15;
   }
   return off;
 }
 
 // LDS budget under which the sparse (LDS-resident) table is used; two workgroups per CU still fit.
-constexpr size_t kGsSparseLdsBudget = 76 * 1024;
+constexpr size_t kGsSparseLdsBudget = 78 * 1024;
 
 struct GsHipError { int code; std::string msg; };
 #define GS_TRY(expr)                                                                      \
@@ -539,7 +605,7 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
     bool sparse = getenv("TOPOLOW_GS_DENSE") == nullptr;
     for (int b = 0; b < count && sparse; ++b) {
       const GsProblem& p = pbs[b];
-      sparse = p.n < 65536 && p.n_edges > 0 &&
+      sparse = p.n <= 2048 && p.n_edges > 0 && p.n_edges < 65535 &&
                gs_lds_bytes(p.n, dim, sizeof(real), p.n_edges) <= kGsSparseLdsBudget &&
                gs_edges_match_matrix(p);
     }
