@@ -140,3 +140,39 @@ def test_torch_encoder_matches_c_encoder():
     w = sharded.encode_words_torch(torch, torch.from_numpy(vals)).numpy()
     for v, got in zip(vals, w):
         assert int(got) == _native.encode_target(float(v), 0)
+
+
+# ---- config 5 fan-out: parameter sets dealt over ranks, results gathered (no data-path collective) ----
+def _fake_sweep(matrix, sets, max_iter, eps, folds, preserve, rng, precision):
+    """CPU stand-in for cv.likelihood_sweep: a deterministic function of the parameter set."""
+    return ([dict(Holdout_MAE=ps["k0"] * 2 + ps["N"], NLL=1.0, mean_iter=3.0, pct_converged=100.0) for ps in sets],
+            0.01 * len(sets), len(sets) * folds)
+
+
+def _run_sweep(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from topolow_amd import cv
+    sets = [dict(N=2 + (s % 3), k0=float(s), cooling_rate=0.01, c_repulsion=0.01) for s in range(7)]
+    res, secs, n_emb = cv.likelihood_sweep_distributed(np.zeros((4, 4)), sets, 10, 1e-4, folds=5, seed=1,
+                                                       batch_fn=_fake_sweep)
+    q.put((rank, [r["Holdout_MAE"] for r in res], n_emb))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_parameter_sweep_fans_out_over_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_sweep, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in range(2)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [float(s) * 2 + 2 + (s % 3) for s in range(7)]
+    for _, maes, n_emb in outs:
+        assert maes == want and n_emb == 35      # every rank holds every result, in the caller's order

@@ -141,6 +141,44 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     return out, secs, len(live)
 
 
+def likelihood_sweep_distributed(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]],
+                                 mapping_max_iter: int, relative_epsilon: float, folds: int = 20,
+                                 preserve_order: bool = False, seed: int = 0, precision: str = "f64",
+                                 batch_fn=None):
+    """BASELINE config 5 across GPUs: the parameter sets of a sweep are dealt round-robin to the
+    ranks of the current torch.distributed group (one process per GPU); every rank relaxes its share
+    as one batched launch on its own device; the per-set results are then all-gathered (a few
+    floats per set -- there is no data-path collective, the embeddings are independent, exactly as
+    in the reference's mclapply fan-out, R/adaptive_sampling.R:666,1301).  Without an initialised
+    process group this is `likelihood_sweep`.  Returns the results in the order of `param_sets`."""
+    rank, world = 0, 1
+    dist = None
+    try:
+        import torch.distributed as dist_mod
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            dist = dist_mod
+            rank, world = dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    mine = list(range(rank, len(param_sets), world))
+    rng = np.random.default_rng([int(seed), rank])
+    fn = batch_fn if batch_fn is not None else likelihood_sweep
+    res, secs, n_emb = fn(dissimilarity_matrix, [param_sets[q] for q in mine], mapping_max_iter,
+                          relative_epsilon, folds, preserve_order, rng, precision) if mine else ([], 0.0, 0)
+    if dist is None or world == 1:
+        return res, secs, n_emb
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, res, secs, n_emb))
+    out = [None] * len(param_sets)
+    total_emb, max_secs = 0, 0.0
+    for idx, rr, sc, ne in gathered:
+        for q, r in zip(idx, rr):
+            out[q] = r
+        total_emb += ne
+        max_secs = max(max_secs, sc)
+    return out, max_secs, total_emb
+
+
 def likelihood_function(dissimilarity_matrix, mapping_max_iter, relative_epsilon, N, k0, cooling_rate,
                         c_repulsion, folds=20, num_cores=1, preserve_order=False):
     """Drop-in for the reference's `likelihood_function()` (R/adaptive_sampling.R:2552-2555):
