@@ -95,14 +95,6 @@ def _is_na(v: np.ndarray) -> np.ndarray:
     return out
 
 
-def _strip_prefix(v: np.ndarray, mask: np.ndarray, pattern: str) -> np.ndarray:
-    """as.numeric(sub(pattern, "", x[mask])) for a character matrix."""
-    rx = re.compile(pattern)
-    cells = v[mask]
-    return np.array([_as_numeric_scalar(rx.sub("", str(c), count=1)) for c in cells],
-                    dtype=np.float64)
-
-
 @dataclass
 class CodedMatrix:
     """Numeric twin of R's character dissimilarity matrix: `values` holds the number of every

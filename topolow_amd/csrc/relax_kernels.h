@@ -23,7 +23,7 @@ constexpr int kWaves = kThreads / 64;
 //   THREADS : workgroup size (waves share one LDS image of the slab's column points)
 //   RPW     : rows (points being moved) per wave; their coordinates sit in SGPRs
 //   CHUNK   : slab columns staged in LDS at a time (multiple of 256)
-//   UPFRONT : 1 = issue a whole chunk's target loads before the LDS staging, 0 = per group
+//   (4th parameter: unused, kept so tuning variants keep their spelling)
 //   ABLATE  : tuning builds only -- 1 = skip the pair arithmetic (memory floor), 2 = skip the
 //             target loads (arithmetic floor); results are wrong on purpose
 //   MINWAVES: second __launch_bounds__ argument (waves per SIMD the register budget must allow)
@@ -220,123 +220,41 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_kernel
 #pragma unroll 1
     for (int cb = rb; cb < re; cb += kChunk) {
       const int cw = min(kChunk, re - cb);  // multiple of 4
-      if constexpr (CFG::UPFRONT) {
-      // Issue this chunk's target words first (kChunk/256 column groups x RPW rows of 16 B per
-      // lane stay in flight), so their HBM latency overlaps the LDS staging below.
-      constexpr int kGroups = kChunk / 256;
-      uint4 w4[kGroups][RPW];
-#pragma unroll
-      for (int t = 0; t < kGroups; ++t) {
-        const int c4 = lane * 4 + t * 256;
-        if (c4 < cw) {
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-            w4[t][r] = *reinterpret_cast<const uint4*>(rowp[r] + cb + c4);
-        }
-      }
       __syncthreads();  // previous chunk fully consumed
-      // stage column points [cb, cb+cw) into LDS, structure-of-arrays; padding columns get a
-      // phantom point far away (see relax_common.h)
       stage_points<DIM, real, CFG::THREADS, kChunk>(pos_in, cb, cw, lds_pos, tid);
       __syncthreads();
+#pragma unroll 1
+      for (int c4 = lane * 4; c4 < cw; c4 += 256) {
+        uint4 w4[RPW];
 #pragma unroll
-      for (int t = 0; t < kGroups; ++t) {
-        const int c4 = lane * 4 + t * 256;
-        if (c4 < cw) {
-          real pc[4][DIM];
-          load_points<DIM, real>(lds_pos, c4, pc);
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) {
-            if (ANYTHR && thr) {
-              pair_accum<DIM, real, true>(pc[0], pi[r], w4[t][r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[1], pi[r], w4[t][r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[2], pi[r], w4[t][r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[3], pi[r], w4[t][r].w, ks[r], cg[r], acc[r]);
-            } else {
-              pair_accum<DIM, real, false>(pc[0], pi[r], w4[t][r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[1], pi[r], w4[t][r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[2], pi[r], w4[t][r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[3], pi[r], w4[t][r].w, ks[r], cg[r], acc[r]);
-            }
+        for (int r = 0; r < RPW; ++r) {
+          if constexpr (CFG::ABLATE == 2) {
+            w4[r] = make_uint4(0x40000000u + c4, 0x40400002u, 0x7f800002u, 0x40800001u);
+          } else {
+            // buffer load: per-row descriptor in SGPRs + one shared 32-bit lane offset
+            w4[r] = load_words(rsrc[r], (cb + c4) * 4);
           }
         }
-      }
-      } else if constexpr (CFG::UPFRONT == 2) {
-        __syncthreads();  // previous chunk fully consumed
-        stage_points<DIM, real, CFG::THREADS, kChunk>(pos_in, cb, cw, lds_pos, tid);
-        // first group's target words are requested before the barrier, each later group one
-        // step ahead of its use
-        uint4 nxt[RPW];
-        if (lane * 4 < cw) {
+        if constexpr (CFG::ABLATE == 1) {
 #pragma unroll
           for (int r = 0; r < RPW; ++r)
-            nxt[r] = *reinterpret_cast<const uint4*>(rowp[r] + cb + lane * 4);
+            acc[r][0] += (float)((w4[r].x ^ w4[r].y ^ w4[r].z ^ w4[r].w) & 1u) * 1e-30f;
+          continue;
         }
-        __syncthreads();
-#pragma unroll 1
-        for (int c4 = lane * 4; c4 < cw; c4 += 256) {
-          uint4 w4[RPW];
+        real pc[4][DIM];
+        load_points<DIM, real>(lds_pos, c4, pc);
 #pragma unroll
-          for (int r = 0; r < RPW; ++r) w4[r] = nxt[r];
-          if (c4 + 256 < cw) {
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-              nxt[r] = *reinterpret_cast<const uint4*>(rowp[r] + cb + c4 + 256);
-          }
-          real pc[4][DIM];
-          load_points<DIM, real>(lds_pos, c4, pc);
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) {
-            if (ANYTHR && thr) {
-              pair_accum<DIM, real, true>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
-            } else {
-              pair_accum<DIM, real, false>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
-            }
-          }
-        }
-      } else {
-        __syncthreads();  // previous chunk fully consumed
-        stage_points<DIM, real, CFG::THREADS, kChunk>(pos_in, cb, cw, lds_pos, tid);
-        __syncthreads();
-#pragma unroll 1
-        for (int c4 = lane * 4; c4 < cw; c4 += 256) {
-          uint4 w4[RPW];
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) {
-            if constexpr (CFG::ABLATE == 2) {
-              w4[r] = make_uint4(0x40000000u + c4, 0x40400002u, 0x7f800002u, 0x40800001u);
-            } else {
-              // buffer load: per-row descriptor in SGPRs + one shared 32-bit lane offset
-              w4[r] = load_words(rsrc[r], (cb + c4) * 4);
-            }
-          }
-          if constexpr (CFG::ABLATE == 1) {
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-              acc[r][0] += (float)((w4[r].x ^ w4[r].y ^ w4[r].z ^ w4[r].w) & 1u) * 1e-30f;
-            continue;
-          }
-          real pc[4][DIM];
-          load_points<DIM, real>(lds_pos, c4, pc);
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) {
-            if (ANYTHR && thr) {
-              pair_accum<DIM, real, true>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
-            } else {
-              pair_accum<DIM, real, false>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
-            }
+        for (int r = 0; r < RPW; ++r) {
+          if (ANYTHR && thr) {
+            pair_accum<DIM, real, true>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
+            pair_accum<DIM, real, true>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
+            pair_accum<DIM, real, true>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
+            pair_accum<DIM, real, true>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
+          } else {
+            pair_accum<DIM, real, false>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
+            pair_accum<DIM, real, false>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
+            pair_accum<DIM, real, false>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
+            pair_accum<DIM, real, false>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
           }
         }
       }
