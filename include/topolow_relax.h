@@ -29,6 +29,7 @@ extern "C" {
 #define TOPOLOW_ERR_NO_DEVICE 4      /* no usable HIP device: there is NO CPU fallback */
 #define TOPOLOW_ERR_HIP 5            /* a HIP runtime call failed; message has the call */
 #define TOPOLOW_ERR_UNSUPPORTED 6
+#define TOPOLOW_ERR_INTERRUPTED 7    /* the caller's interrupt callback asked to stop */
 
 /* Schedules (topolow_options.schedule). */
 #define TOPOLOW_SCHEDULE_AUTO 0   /* GS tournament for n <= gs_max_n, slab above */
@@ -49,6 +50,12 @@ typedef struct topolow_options {
   int32_t device;       /* HIP device ordinal; -1 = current device */
   int32_t gs_max_n;     /* AUTO switches to the slab schedule above this n; 0 = default */
   int32_t reserved[5];
+  /* Polled every 50 iterations like Rcpp::checkUserInterrupt() in the reference
+   * (src/optimization.cpp:364); a non-zero return abandons the run with TOPOLOW_ERR_INTERRUPTED
+   * after device memory has been released.  NULL = never.  (Multi-workgroup schedules only: the
+   * one-workgroup GS kernel is a single launch.) */
+  int32_t (*interrupt_cb)(void* user);
+  void* interrupt_user;
 } topolow_options;
 
 /* Run statistics, filled by topolow_optimize_layout_exact when `stats` is non-NULL. */

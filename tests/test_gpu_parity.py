@@ -443,3 +443,20 @@ def test_tile_gs_through_the_call_boundary_and_statistics():
     assert abs(got.final_mae - slab.final_mae) <= 0.08 * got.final_mae
     sm, cnt = orc.edge_error(got.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
     assert got.final_mae == pytest.approx(sm / cnt, rel=1e-10)
+
+
+def test_interrupt_callback_and_verbose(capfd):
+    """reference :364 (interrupt poll every 50 iterations) and :183-188/:298-301 (verbose progress)."""
+    call, _ = _random_problem(1200, 3, 0.7, seed=12, n_iter=400)
+    calls = []
+
+    def stop_after_two():
+        calls.append(1)
+        return len(calls) >= 2
+    with pytest.raises(_native.NativeError) as ei:
+        _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1, schedule="slab",
+                                             interrupt=stop_after_two)
+    assert ei.value.code == _native.ERR_INTERRUPTED and len(calls) == 2
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), True, seed=1, schedule="slab")
+    out = capfd.readouterr().out
+    assert "Points: 1200" in out and "Iter " in out and "topolow_relax[slab]" in out and got.iterations > 0

@@ -22,8 +22,8 @@ PRECISION_AUTO, PRECISION_F32, PRECISION_F64 = 0, 1, 2
 FAR_F32 = 1.0e18   # phantom coordinate of padding points (relax_common.h)
 
 OK = 0
-ERR_TOO_FEW_POINTS, ERR_NONFINITE, ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = \
-    1, 2, 3, 4, 5, 6
+ERR_TOO_FEW_POINTS, ERR_NONFINITE, ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, \
+    ERR_INTERRUPTED = 1, 2, 3, 4, 5, 6, 7
 
 
 class NativeError(RuntimeError):
@@ -34,10 +34,13 @@ class NativeError(RuntimeError):
         self.code = code
 
 
+INTERRUPT_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+
+
 class TopolowOptions(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("schedule", C.c_int32), ("precision", C.c_int32),
                 ("slab_stages", C.c_int32), ("device", C.c_int32), ("gs_max_n", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("reserved", C.c_int32 * 5), ("interrupt_cb", INTERRUPT_CB), ("interrupt_user", C.c_void_p)]
 
 
 class TopolowRunStats(C.Structure):
@@ -238,6 +241,10 @@ def make_options(**kw) -> TopolowOptions:
     o.slab_stages = int(cfg.get("slab_stages", 0) or 0)
     o.device = int(cfg.get("device", -1))
     o.gs_max_n = int(cfg.get("gs_max_n", 0) or 0)
+    cb = cfg.get("interrupt")
+    if cb is not None:   # Python callable() -> truthy to stop; keep a reference alive on the struct
+        o._cb_keepalive = INTERRUPT_CB(lambda _user: 1 if cb() else 0)
+        o.interrupt_cb = o._cb_keepalive
     return o
 
 

@@ -478,6 +478,8 @@ void topolow_default_options(topolow_options* opt) {
   opt->slab_stages = 0;
   opt->device = -1;
   opt->gs_max_n = 0;
+  opt->interrupt_cb = nullptr;
+  opt->interrupt_user = nullptr;
 }
 
 uint32_t topolow_encode_target(double dissimilarity, int32_t threshold_code) {
@@ -1151,10 +1153,31 @@ int topolow_optimize_layout_exact(
                                opt.slab_stages, errbuf, errlen);
     if (rc) break;
     t_dev0 = now_s();
+    if (verbose) {
+      std::printf("=== %s schedule on HIP device %d ===\n", tile_gs ? "Exact tile Gauss-Seidel" : "Slab",
+                  s->device);
+      std::printf("Points: %d, Pairs per iteration: %lld\n", n, (long long)n * (n - 1) / 2);
+      std::printf("Parameters: k0=%g, cooling=%g, c_rep=%g\n", k0, cooling_rate, c_repulsion);
+    }
+    int last_reported = 0;
     for (;;) {
       int enq = 0;
-      rc = topolow_session_enqueue(s, 64, &enq, errbuf, errlen);
+      // 50 iterations at a time: the reference's interrupt cadence (src/optimization.cpp:364)
+      rc = topolow_session_enqueue(s, 50, &enq, errbuf, errlen);
       if (rc || enq == 0) break;
+      if (opt.interrupt_cb && opt.interrupt_cb(opt.interrupt_user)) {
+        set_err(errbuf, errlen, "interrupted by the caller");
+        rc = TOPOLOW_ERR_INTERRUPTED;
+        break;
+      }
+      if (verbose) {  // progress like the reference's Rcout lines (:298-301), one per 50 iterations
+        int it = 0, stp = 0;
+        double mae = 0.0;
+        if (topolow_session_sync(s, &it, &stp, &mae, nullptr, 0) == TOPOLOW_OK && it != last_reported) {
+          std::printf("Iter %d/%d, MAE=%g\n", it, n_iter, mae);
+          last_reported = it;
+        }
+      }
     }
     if (rc) break;
     double last = 0.0;

@@ -21,6 +21,14 @@
 
 #include "topolow_relax.h"
 
+/* R_CheckUserInterrupt() longjmps; probing it through R_ToplevelExec keeps control here so the
+ * library can release its device memory before the interrupt is re-raised. */
+static void probe_interrupt(void* dummy) { (void)dummy; R_CheckUserInterrupt(); }
+static int32_t interrupt_pending(void* user) {
+  (void)user;
+  return R_ToplevelExec(probe_interrupt, NULL) == FALSE;
+}
+
 static int opt_int(const char* name, int dflt) {
   SEXP v = Rf_GetOption1(Rf_install(name));
   if (v == R_NilValue || Rf_length(v) < 1) return dflt;
@@ -73,6 +81,7 @@ SEXP _topolow_optimize_layout_exact_cpp(SEXP initial_positionsSEXP, SEXP dissimi
   opt.device = opt_int("topolow.device", -1);
   opt.slab_stages = opt_int("topolow.slab_stages", 0);
   opt.gs_max_n = opt_int("topolow.gs_max_n", 0);
+  opt.interrupt_cb = interrupt_pending;   /* polled every 50 iterations, reference :364 */
 
   SEXP positions = PROTECT(Rf_allocMatrix(REALSXP, n, ndim));
   int converged = 0, iterations = 0;
@@ -93,6 +102,7 @@ SEXP _topolow_optimize_layout_exact_cpp(SEXP initial_positionsSEXP, SEXP dissimi
   if (rc != TOPOLOW_OK) {
     UNPROTECT(1);
     /* every device buffer is already released inside the library */
+    if (rc == TOPOLOW_ERR_INTERRUPTED) Rf_onintr();   /* re-raise the user's interrupt */
     Rf_error("%s", err[0] ? err : "libtopolow_relax failed");
   }
 
