@@ -314,6 +314,12 @@ __device__ __forceinline__ void pair_error(const real (&pc)[DIM], const real (&p
   cnt += contributes ? 1u : 0u;
 }
 
+// Grid: x = column chunk (CFG::CHUNK columns), y = row tile (kErrTileRows rows).  A workgroup stages
+// its chunk's points into LDS ONCE and sweeps the tile's rows over it (RPW rows per wave at a
+// time), so the staging is amortised over kErrTileRows rows; tiles that hold no pair to reduce
+// (left of the diagonal in upper-triangle mode) write a zero partial and leave.
+constexpr int kErrTileRows = 64;
+
 template <int DIM, typename real, typename CFG, bool PARITY>
 __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
     const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
@@ -325,69 +331,72 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
   constexpr int RPW = CFG::RPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char slab_smem[];
   real* lds_pos = reinterpret_cast<real*>(slab_smem);
+  __shared__ double sh_s[CFG::WAVES];
+  __shared__ unsigned long long sh_c[CFG::WAVES];
 
-  static_assert(PARITY || RPW == 2, "the upper-triangle pass folds rows in pairs");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n4 = (n + 3) & ~3;
-  // Upper-triangle mode: row i reduces n-1-i pairs, so a wave takes one row from the top of the
-  // block and its mirror from the bottom -- every wave then reduces about the same number of
-  // pairs and no workgroup straggles.  Parity mode rows are balanced as they are.
-  const int n_rows = row_end - row_begin;
-  const int widx = blockIdx.x * CFG::WAVES + wave;   // wave index in the grid
-  int wave_rows[RPW];
-  if constexpr (PARITY) {
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) wave_rows[r] = row_begin + widx * RPW + r;
-  } else {
-    wave_rows[0] = row_begin + widx;
-    wave_rows[1] = row_end - 1 - widx;
-    if (wave_rows[1] <= wave_rows[0]) wave_rows[1] = 0x7fffffff;      // odd middle row: once
-    if (widx >= (n_rows + 1) / 2) wave_rows[0] = 0x7fffffff;
+  const int part = blockIdx.y * gridDim.x + blockIdx.x;
+  const int cb = blockIdx.x * kChunk;
+  const int tile_row0 = row_begin + blockIdx.y * kErrTileRows;
+  const int cw = min(kChunk, n4 - cb);
+  // upper-triangle mode: the tile holds a pair (i, c > i) only if its last column lies right of its
+  // first row
+  if (cw <= 0 || tile_row0 >= row_end || (!PARITY && cb + cw - 1 <= tile_row0)) {
+    if (tid == 0) { part_sum[part] = 0.0; part_cnt[part] = 0; }
+    return;
   }
-  const int wg_row0 = PARITY ? 0 : row_begin + blockIdx.x * CFG::WAVES;  // smallest row of the WG
-
-  real pi[RPW][DIM];
-  const uint32_t* rowp[RPW];
-  int rows[RPW];
-  int thr_any = 0;
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int row = wave_rows[r];
-    const int rr = row < row_end ? row : row_end - 1;
-    rows[r] = row < row_end ? row : 0x7fffffff;  // out-of-range rows take no pair
-    thr_any |= rowflags[rr - row_begin];
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) pi[r][d] = uniform(pos[(size_t)rr * DIM + d]);
-    rowp[r] = denc + (size_t)(rr - row_begin) * ld;
-  }
-  row_rsrc_t rsrc[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) rsrc[r] = make_row_rsrc(rowp[r], ld);
-  const bool thr = __builtin_amdgcn_readfirstlane(thr_any) != 0;
+  stage_points<DIM, real, CFG::THREADS, kChunk>(pos, cb, cw, lds_pos, tid);
+  __syncthreads();
 
   float err = 0.0f;
   unsigned cnt = 0;
   double err_d = 0.0;
-  // first column any row of this workgroup needs (upper-triangle mode), chunk aligned
-  const int c_first = PARITY ? 0 : ((wg_row0 + 1) / kChunk) * kChunk;
 #pragma unroll 1
-  for (int cb = c_first; cb < n4; cb += kChunk) {
-    const int cw = min(kChunk, n4 - cb);
-    __syncthreads();
-    stage_points<DIM, real, CFG::THREADS, kChunk>(pos, cb, cw, lds_pos, tid);
-    __syncthreads();
-#pragma unroll 1
-    for (int c4 = lane * 4; c4 < cw; c4 += 256) {
+  for (int sub = 0; sub < kErrTileRows; sub += CFG::ROWS) {
+    const int row0 = tile_row0 + sub + wave * RPW;
+    if (row0 >= row_end) break;                        // wave-uniform
+    if (!PARITY && cb + cw - 1 <= row0) continue;      // these rows lie right of the whole chunk
+    real pi[RPW][DIM];
+    int rows[RPW];
+    row_rsrc_t rsrc[RPW];
+    int thr_any = 0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int row = row0 + r;
+      const int rr = row < row_end ? row : row_end - 1;
+      rows[r] = row < row_end ? row : 0x7fffffff;      // out-of-range rows take no pair
+      thr_any |= rowflags[rr - row_begin];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) pi[r][d] = uniform(pos[(size_t)rr * DIM + d]);
+      rsrc[r] = make_row_rsrc(denc + (size_t)(rr - row_begin) * ld, ld);
+    }
+    const bool thr = __builtin_amdgcn_readfirstlane(thr_any) != 0;
+    // all of this row batch's target words are requested before any is used (the points are
+    // already in LDS, so nothing queues behind these loads)
+    constexpr int kGroups = kChunk / 256;
+    uint4 w4[kGroups][RPW];
+#pragma unroll
+    for (int t = 0; t < kGroups; ++t) {
+      const int c4 = lane * 4 + t * 256;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const bool need = c4 < cw && (PARITY || cb + c4 + 3 > rows[r]) && rows[r] != 0x7fffffff;
+        w4[t][r] = need ? load_words(rsrc[r], (cb + c4) * 4) : make_uint4(kInfWord, kInfWord, kInfWord, kInfWord);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kGroups; ++t) {
+      const int c4 = lane * 4 + t * 256;
+      if (c4 >= cw) continue;
       const int col = cb + c4;
       real pc[4][DIM];
       load_points<DIM, real>(lds_pos, c4, pc);
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const int i = rows[r];
-        if (!PARITY && col + 3 <= i) continue;  // whole group left of the diagonal (wave-varying, cheap)
-        const uint4 w4 = load_words(rsrc[r], col * 4);
         bool take[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -400,25 +409,23 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
           }
         }
         if (thr) {
-          pair_error<DIM, real, true>(pc[0], pi[r], w4.x, take[0], err, cnt);
-          pair_error<DIM, real, true>(pc[1], pi[r], w4.y, take[1], err, cnt);
-          pair_error<DIM, real, true>(pc[2], pi[r], w4.z, take[2], err, cnt);
-          pair_error<DIM, real, true>(pc[3], pi[r], w4.w, take[3], err, cnt);
+          pair_error<DIM, real, true>(pc[0], pi[r], w4[t][r].x, take[0], err, cnt);
+          pair_error<DIM, real, true>(pc[1], pi[r], w4[t][r].y, take[1], err, cnt);
+          pair_error<DIM, real, true>(pc[2], pi[r], w4[t][r].z, take[2], err, cnt);
+          pair_error<DIM, real, true>(pc[3], pi[r], w4[t][r].w, take[3], err, cnt);
         } else {
-          pair_error<DIM, real, false>(pc[0], pi[r], w4.x, take[0], err, cnt);
-          pair_error<DIM, real, false>(pc[1], pi[r], w4.y, take[1], err, cnt);
-          pair_error<DIM, real, false>(pc[2], pi[r], w4.z, take[2], err, cnt);
-          pair_error<DIM, real, false>(pc[3], pi[r], w4.w, take[3], err, cnt);
+          pair_error<DIM, real, false>(pc[0], pi[r], w4[t][r].x, take[0], err, cnt);
+          pair_error<DIM, real, false>(pc[1], pi[r], w4[t][r].y, take[1], err, cnt);
+          pair_error<DIM, real, false>(pc[2], pi[r], w4[t][r].z, take[2], err, cnt);
+          pair_error<DIM, real, false>(pc[3], pi[r], w4[t][r].w, take[3], err, cnt);
         }
       }
     }
-    // fold the fp32 running sum into f64 once per chunk (<= 8*RPW terms per lane before that)
+    // fold the fp32 running sum into f64 once per row batch (<= 16*RPW terms per lane before that)
     err_d += (double)err;
     err = 0.0f;
   }
 
-  __shared__ double sh_s[CFG::WAVES];
-  __shared__ unsigned long long sh_c[CFG::WAVES];
   double s = wave_sum<double>(err_d);
   unsigned long long c64 = cnt;
 #pragma unroll
@@ -429,8 +436,8 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
     double ts = 0.0;
     unsigned long long tc = 0;
     for (int w = 0; w < CFG::WAVES; ++w) { ts += sh_s[w]; tc += sh_c[w]; }
-    part_sum[blockIdx.x] = ts;
-    part_cnt[blockIdx.x] = tc;
+    part_sum[part] = ts;
+    part_cnt[part] = tc;
   }
 }
 

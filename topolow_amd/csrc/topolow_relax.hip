@@ -122,7 +122,7 @@ struct topolow_session {
   int n_parts = 0;
   bool dense_mae = false;   // edge list verified == measured cells of the encoded block
   bool dense_parity = false;
-  int dense_blocks = 0;
+  int dense_blocks = 0, dense_grid_x = 0, dense_grid_y = 0;
   DevBuf<double> part_sum;
   DevBuf<unsigned long long> part_cnt;
   DevBuf<RunState> state;
@@ -272,16 +272,15 @@ using ErrCfg = StageCfg<256, 2, 1024>;
 template <int DIM, typename real>
 void launch_dense_error(topolow_session* s, const void* pos, const RunState* st) {
   const size_t lds = sizeof(real) * DIM * ErrCfg::CHUNK;
+  const dim3 grid(s->dense_grid_x, s->dense_grid_y);
   if (s->dense_parity) {
-    hipLaunchKernelGGL((dense_error_kernel<DIM, real, ErrCfg, true>), dim3(s->dense_blocks),
-                       dim3(ErrCfg::THREADS), lds, s->stream, s->enc.p, s->ld, s->row_begin,
-                       s->row_end, s->n, (const real*)pos, s->rowflags.p, s->part_sum.p,
-                       s->part_cnt.p, st);
+    hipLaunchKernelGGL((dense_error_kernel<DIM, real, ErrCfg, true>), grid, dim3(ErrCfg::THREADS), lds,
+                       s->stream, s->enc.p, s->ld, s->row_begin, s->row_end, s->n, (const real*)pos,
+                       s->rowflags.p, s->part_sum.p, s->part_cnt.p, st);
   } else {
-    hipLaunchKernelGGL((dense_error_kernel<DIM, real, ErrCfg, false>), dim3(s->dense_blocks),
-                       dim3(ErrCfg::THREADS), lds, s->stream, s->enc.p, s->ld, s->row_begin,
-                       s->row_end, s->n, (const real*)pos, s->rowflags.p, s->part_sum.p,
-                       s->part_cnt.p, st);
+    hipLaunchKernelGGL((dense_error_kernel<DIM, real, ErrCfg, false>), grid, dim3(ErrCfg::THREADS), lds,
+                       s->stream, s->enc.p, s->ld, s->row_begin, s->row_end, s->n, (const real*)pos,
+                       s->rowflags.p, s->part_sum.p, s->part_cnt.p, st);
   }
 }
 
@@ -686,8 +685,10 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     s->n_parts = (int)blocks;
-    // upper-triangle mode folds two rows per wave; parity mode takes RPW consecutive rows
-    s->dense_blocks = (s->rows() + ErrCfg::ROWS - 1) / ErrCfg::ROWS + 1;
+    // dense MAE pass: one workgroup per (column chunk, 64-row tile)
+    s->dense_grid_x = (((s->n + 3) & ~3) + ErrCfg::CHUNK - 1) / ErrCfg::CHUNK;
+    s->dense_grid_y = (s->rows() + kErrTileRows - 1) / kErrTileRows;
+    s->dense_blocks = s->dense_grid_x * s->dense_grid_y;
     s->part_sum.alloc(std::max(s->n_parts, s->dense_blocks));
     s->part_cnt.alloc(std::max(s->n_parts, s->dense_blocks));
     // Can the MAE be reduced from the encoded block instead of gathering the edge list?  Only if
