@@ -23,7 +23,7 @@ constexpr int kWaves = kThreads / 64;
 //   THREADS : workgroup size (waves share one LDS image of the slab's column points)
 //   RPW     : rows (points being moved) per wave; their coordinates sit in SGPRs
 //   CHUNK   : slab columns staged in LDS at a time (multiple of 256)
-//   (4th parameter: unused, kept so tuning variants keep their spelling)
+//   UPFRONT : 1 = request a whole chunk's target words right after the staging barrier
 //   ABLATE  : tuning builds only -- 1 = skip the pair arithmetic (memory floor), 2 = skip the
 //             target loads (arithmetic floor); results are wrong on purpose
 //   MINWAVES: second __launch_bounds__ argument (waves per SIMD the register budget must allow)
@@ -223,6 +223,41 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_kernel
       __syncthreads();  // previous chunk fully consumed
       stage_points<DIM, real, CFG::THREADS, kChunk>(pos_in, cb, cw, lds_pos, tid);
       __syncthreads();
+      if constexpr (CFG::UPFRONT == 1) {
+        // all target words of the chunk are requested right after the staging barrier, then
+        // consumed group by group (one exposed latency per chunk instead of one per group)
+        constexpr int kGroups = kChunk / 256;
+        uint4 wa[kGroups][RPW];
+#pragma unroll
+        for (int t = 0; t < kGroups; ++t) {
+          const int c4 = lane * 4 + t * 256;
+#pragma unroll
+          for (int r = 0; r < RPW; ++r)
+            wa[t][r] = c4 < cw ? load_words(rsrc[r], (cb + c4) * 4)
+                               : make_uint4(kInfWord, kInfWord, kInfWord, kInfWord);
+        }
+#pragma unroll
+        for (int t = 0; t < kGroups; ++t) {
+          const int c4 = lane * 4 + t * 256;
+          if (c4 >= cw) continue;
+          real pc[4][DIM];
+          load_points<DIM, real>(lds_pos, c4, pc);
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            if (ANYTHR && thr) {
+              pair_accum<DIM, real, true>(pc[0], pi[r], wa[t][r].x, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[1], pi[r], wa[t][r].y, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[2], pi[r], wa[t][r].z, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, true>(pc[3], pi[r], wa[t][r].w, ks[r], cg[r], acc[r]);
+            } else {
+              pair_accum<DIM, real, false>(pc[0], pi[r], wa[t][r].x, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[1], pi[r], wa[t][r].y, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[2], pi[r], wa[t][r].z, ks[r], cg[r], acc[r]);
+              pair_accum<DIM, real, false>(pc[3], pi[r], wa[t][r].w, ks[r], cg[r], acc[r]);
+            }
+          }
+        }
+      } else
 #pragma unroll 1
       for (int c4 = lane * 4; c4 < cw; c4 += 256) {
         uint4 w4[RPW];

@@ -206,6 +206,9 @@ using CfgB = StageCfg<512, 2, 1024>;            // 16 rows / WG, twice the waves
 using CfgC = StageCfg<512, 2, 2560>;            // whole 10k/4 slab in one LDS image
 using CfgD = StageCfg<256, 2, 1024>;            // production geometry without the register budget
 using CfgE = StageCfg<512, 4, 1024>;            // 32 rows / WG
+using CfgF = StageCfg<256, 2, 1024, 1, 0, 4>;   // chunk loads up front, 4 waves/SIMD
+using CfgL = StageCfg<256, 2, 1024, 1, 0, 5>;   // chunk loads up front, 5 waves/SIMD
+using CfgM = StageCfg<256, 2, 512, 1, 0, 5>;    // 512-column chunks, loads up front
 using CfgG = StageCfg<256, 2, 1024, 0, 1>;      // memory only   (results wrong on purpose)
 using CfgH = StageCfg<256, 2, 1024, 0, 2>;      // arithmetic only (results wrong on purpose)
 using CfgI = StageCfg<256, 2, 1024, 0, 0, 8>;   // squeezed to 64 VGPRs
@@ -253,6 +256,9 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
       case 2: launch_stage_cfg<DIM, float, CfgC>(s, pin, pout, st, rg, iter1, k); break;
       case 3: launch_stage_cfg<DIM, float, CfgD>(s, pin, pout, st, rg, iter1, k); break;
       case 4: launch_stage_cfg<DIM, float, CfgE>(s, pin, pout, st, rg, iter1, k); break;
+      case 5: launch_stage_cfg<DIM, float, CfgF>(s, pin, pout, st, rg, iter1, k); break;
+      case 11: launch_stage_cfg<DIM, float, CfgL>(s, pin, pout, st, rg, iter1, k); break;
+      case 12: launch_stage_cfg<DIM, float, CfgM>(s, pin, pout, st, rg, iter1, k); break;
       case 6: launch_stage_cfg<DIM, float, CfgG>(s, pin, pout, st, rg, iter1, k); break;
       case 7: launch_stage_cfg<DIM, float, CfgH>(s, pin, pout, st, rg, iter1, k); break;
       case 8: launch_stage_cfg<DIM, float, CfgI>(s, pin, pout, st, rg, iter1, k); break;
