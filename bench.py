@@ -12,7 +12,7 @@ convergence check the reference runs every `convergence_check_freq`=3 iterations
           ONE embedding row-block sharded over the ranks (all-gather of position slices after
           every slab stage over RCCL) => "scaling": "strong".
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (slab_stage_kernel):
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (slab_stage_pipe_kernel):
 algorithmic bytes per launch = (4*rows*N + 8*N*ndim + 4*N) / stages, divided by its mean
 duration from HIP events recorded on the session stream around every launch in a separate
 profiled pass.  `cpu_baseline` times the CPU oracle (reference schedule, 1 core) on a bounded
@@ -121,7 +121,7 @@ def run_single(args):
             raise ValueError("the committed PMC run is for the config-3 size only")
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
             for name, vals in json.load(fh).items():
-                if "slab_stage_kernel<5, float" in name and "hbm_traffic_bytes_per_launch" in vals:
+                if "slab_stage_" in name and "<5, float" in name and "hbm_traffic_bytes_per_launch" in vals:
                     traffic = vals["hbm_traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -153,7 +153,7 @@ def run_single(args):
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                        "separate passes, FETCH_SIZE x2 on gfx950)" if traffic else None,
-                     "kernel": "slab_stage_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
+                     "kernel": "slab_stage_pipe_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
                      "timing": "HIP events on the session stream around every stage launch, in a second "
                                "pass of the same K iterations (inside the timed pass the events themselves "
                                "cost ~19% throughput); rocprofv3 kernel-trace mean: profiles/r01_kernel_stats.csv",

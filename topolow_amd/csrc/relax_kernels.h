@@ -145,7 +145,10 @@ __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&p
   }
   const real r = Math<real>::sqrt(s);
   const real inv = Math<real>::rcp(r + (real)0.01);
-  const real t = (real)bits_f32(w & ~kCodeMask);
+  // THR = false: every measured word is an exact target (code 0: the word IS the float) and every
+  // other word is kInfWord, so the raw word is class-tested (one instruction) and never masked; the NaN an
+  // unmeasured word reads as only ever reaches the unselected side of the select below
+  const real t = (real)bits_f32(THR ? (w & ~kCodeMask) : w);
   bool spring;
   if constexpr (THR) {
     // branch-free classification (bitwise ops on purpose: no short-circuit control flow);
@@ -153,7 +156,7 @@ __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&p
     const uint32_t code = w & kCodeMask;
     spring = (code == 0u) | ((code == 1u) & (r < t)) | ((code == 2u) & (r > t));
   } else {
-    spring = t < (real)INFINITY;
+    spring = __builtin_amdgcn_classf(bits_f32(w), 0x1f8);   // finite of either sign
   }
   const real fs = (t - r) * inv * ks;
   const real fr = inv * inv * inv * cg;
@@ -313,6 +316,239 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_kernel
       if (!finite && st != nullptr) atomicMin(&st->first_nonfinite, iter1);
     }
   }
+}
+
+#ifdef TOPOLOW_TUNING
+// Tuning builds: per-workgroup start/end stamps (100 MHz constant clock) of the stage kernel's last
+// launch, for the dispatch-ramp / tail analysis in DESIGN.md section 6.
+__device__ unsigned long long* g_wg_stamps = nullptr;
+#define TL_WG_STAMP(slot) \
+  do { if (g_wg_stamps != nullptr && threadIdx.x == 0) g_wg_stamps[blockIdx.x * 2 + (slot)] = wall_clock64(); } while (0)
+#else
+#define TL_WG_STAMP(slot) do { } while (0)
+#endif
+
+// ----------------------------------------------------------------------------------------
+// Pipelined form of the stage kernel (the production one).  Same arithmetic and the same
+// summation order as slab_stage_kernel -- lane l of a wave takes columns 4l..4l+3 of every
+// 256-column group, groups in slab order -- but nothing in the steady state waits for memory:
+//   * the slab's column points move HBM/L2 -> LDS with direct-to-LDS loads (no registers), one
+//     chunk ahead, into the other half of a double buffer: one barrier per chunk, no exposed
+//     staging;
+//   * the encoded target words are requested one 256-column group ahead, across chunk and
+//     slab-part boundaries, so the 4 N^2-byte stream never drains at a barrier.
+// A chunk is GPC groups (CFG::CHUNK / 256, or as many as keep the double buffer near 20 KB).  A 256-column group of points is DIM*sizeof(real)/4 KB, i.e. that many 1-KB wave
+// transfers, dealt round-robin to the waves.
+typedef __attribute__((address_space(3))) const unsigned char* lds_cptr_t;
+
+template <int DIM, typename real, int CHUNK_REQ = 0>
+struct PipeGeom {
+  static constexpr int kGroupBytes = 256 * DIM * (int)sizeof(real);
+  static constexpr int kGpcRaw = CHUNK_REQ > 0 ? CHUNK_REQ / 256 : 10240 / kGroupBytes;
+  static constexpr int GPC = kGpcRaw < 1 ? 1 : (kGpcRaw > 4 ? 4 : kGpcRaw);
+  static constexpr int CHUNK = 256 * GPC;
+  static constexpr int kBufBytes = GPC * kGroupBytes;
+  static constexpr int kXfersPerGroup = kGroupBytes / 1024;
+};
+
+// chunk `c` of the slab: parts [b0,e0) then [b1,e1), CHUNK columns at a time; width 0 past the end
+template <int CHUNK>
+__device__ __forceinline__ void pipe_chunk_at(const SlabRanges& rg, int nc0, int c, int& cb, int& cw) {
+  if (c < nc0) {
+    cb = rg.b0 + c * CHUNK;
+    cw = min(CHUNK, rg.e0 - cb);
+  } else {
+    cb = rg.b1 + (c - nc0) * CHUNK;
+    cw = max(0, min(CHUNK, rg.e1 - cb));
+  }
+}
+
+// Request the points of columns [cb, cb+CHUNK) into `buf` (completion is awaited by the caller's
+// barrier).  A ragged chunk is requested whole -- no control flow; what lies past its last column
+// is never read back -- with the addresses clamped to the position buffer's last 16 bytes.
+template <int DIM, typename real, int WAVES, int CHUNK_REQ>
+__device__ __forceinline__ void pipe_request_points(const real* __restrict__ pos, int pos_bytes,
+                                                    int cb, int cw, unsigned char* buf, int wave,
+                                                    int lane) {
+  using G = PipeGeom<DIM, real, CHUNK_REQ>;
+  const int base = cb * DIM * (int)sizeof(real);
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(pos);
+  (void)cw;
+#pragma unroll
+  for (int x = 0; x < (G::GPC * G::kXfersPerGroup + WAVES - 1) / WAVES; ++x) {
+    const int t = x * WAVES + wave;               // wave-uniform transfer index
+    if ((G::GPC * G::kXfersPerGroup) % WAVES == 0 || t < G::GPC * G::kXfersPerGroup) {
+      const int off = min(base + t * 1024 + lane * 16, pos_bytes - 16);
+      const unsigned lds_dst = (unsigned)(unsigned long)(lds_cptr_t)(buf + t * 1024);
+      // Written as asm on purpose: hipcc drains vmcnt to 0 at every barrier while it knows of an
+      // LDS transfer in flight, which would also drain the target-word prefetch.  The wave that
+      // issues a transfer awaits it itself (pipe_await_points) before the barrier.
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(src + off), "s"(lds_dst) : "memory", "m0");
+    }
+  }
+}
+
+// Wait until this wave's point transfers have landed, leaving its YOUNGER vector-memory operations
+// (the kYounger target loads issued since) in flight: vmcnt counts in issue order.
+template <int kYounger>
+__device__ __forceinline__ void pipe_await_points() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kYounger) : "memory");
+}
+
+template <int DIM, typename real, int RPW, bool ANYTHR>
+struct PipeRows {
+  real pi[RPW][DIM];
+  real acc[RPW][DIM];
+  real ks[RPW], cg[RPW];
+  row_rsrc_t rsrc[RPW];
+  bool thr;
+};
+
+// One chunk: request the next chunk's points into `oth`, sweep this chunk's groups out of `cur`.
+//   w : target words of this chunk's groups on entry, of the next chunk's groups on exit -- a
+//       group's words are requested GPC-1 groups and one barrier before their use
+template <int DIM, typename real, typename CFG, bool ANYTHR>
+__device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>& R,
+                                           const real* __restrict__ pos, int pos_bytes,
+                                           const unsigned char* cur, unsigned char* oth, int cw,
+                                           int ncb, int ncw,
+                                           uint4 (&w)[PipeGeom<DIM, real, CFG::CHUNK>::GPC][CFG::RPW], int wave,
+                                           int lane) {
+  using G = PipeGeom<DIM, real, CFG::CHUNK>;
+  constexpr int RPW = CFG::RPW;
+  if (ncw > 0) pipe_request_points<DIM, real, CFG::WAVES, CFG::CHUNK>(pos, pos_bytes, ncb, ncw, oth, wave, lane);
+  const real* lds_pos = reinterpret_cast<const real*>(cur);
+#pragma unroll
+  for (int g = 0; g < G::GPC; ++g) {
+    const int c4 = lane * 4 + g * 256;
+    if (c4 < cw) {
+      real pc[4][DIM];
+      load_points<DIM, real>(lds_pos, c4, pc);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if (ANYTHR && R.thr) {
+          pair_accum<DIM, real, true>(pc[0], R.pi[r], w[g][r].x, R.ks[r], R.cg[r], R.acc[r]);
+          pair_accum<DIM, real, true>(pc[1], R.pi[r], w[g][r].y, R.ks[r], R.cg[r], R.acc[r]);
+          pair_accum<DIM, real, true>(pc[2], R.pi[r], w[g][r].z, R.ks[r], R.cg[r], R.acc[r]);
+          pair_accum<DIM, real, true>(pc[3], R.pi[r], w[g][r].w, R.ks[r], R.cg[r], R.acc[r]);
+        } else {
+          pair_accum<DIM, real, false>(pc[0], R.pi[r], w[g][r].x, R.ks[r], R.cg[r], R.acc[r]);
+          pair_accum<DIM, real, false>(pc[1], R.pi[r], w[g][r].y, R.ks[r], R.cg[r], R.acc[r]);
+          pair_accum<DIM, real, false>(pc[2], R.pi[r], w[g][r].z, R.ks[r], R.cg[r], R.acc[r]);
+          pair_accum<DIM, real, false>(pc[3], R.pi[r], w[g][r].w, R.ks[r], R.cg[r], R.acc[r]);
+        }
+      }
+    }
+    // The same group of the next chunk, requested as soon as this group's words are dead (so they
+    // land in the same registers).  Unconditional: the count of loads per chunk is what
+    // pipe_await_points relies on; past the slab's end the offset is out of range, which a buffer
+    // load answers with 0 without touching memory.
+    const int noff = g * 256 < ncw ? (ncb + c4) * 4 : 0x7ffffff0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) w[g][r] = load_words(R.rsrc[r], noff);
+  }
+  pipe_await_points<G::GPC * RPW>();
+  __syncthreads();   // next chunk's points have landed; every wave is done reading `cur`
+}
+
+template <int DIM, typename real, typename CFG, bool ANYTHR>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_kernel(
+    const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
+    const real* __restrict__ pos_in, real* __restrict__ pos_out,
+    const float* __restrict__ gplus, const unsigned char* __restrict__ rowflags, RunState* st,
+    SlabRanges rg, int iter1, double k, double c_rep) {
+  if (st != nullptr && st->stopped) return;
+  TL_WG_STAMP(0);
+  using G = PipeGeom<DIM, real, CFG::CHUNK>;
+  constexpr int RPW = CFG::RPW;
+  __shared__ __attribute__((aligned(16))) unsigned char bufs[2 * G::kBufBytes];   // double buffer
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = row_begin + blockIdx.x * CFG::ROWS + wave * RPW;
+  const int pos_bytes = ((n + 3) & ~3) * DIM * (int)sizeof(real);
+  const int nc0 = (rg.e0 - rg.b0 + G::CHUNK - 1) / G::CHUNK;
+  const int nch = nc0 + (rg.e1 - rg.b1 + G::CHUNK - 1) / G::CHUNK;
+
+  PipeRows<DIM, real, RPW, ANYTHR> R;
+  int rr[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r;
+    rr[r] = row < row_end ? row : row_end - 1;  // clamp: result discarded below
+    R.rsrc[r] = make_row_rsrc(denc + (size_t)(rr[r] - row_begin) * ld, ld);
+  }
+  // first chunk's points and target words are on their way before anything else
+  int cb, cw;
+  pipe_chunk_at<G::CHUNK>(rg, nc0, 0, cb, cw);
+  pipe_request_points<DIM, real, CFG::WAVES, CFG::CHUNK>(pos_in, pos_bytes, cb, cw, bufs, wave, lane);
+  uint4 w[G::GPC][RPW];
+#pragma unroll
+  for (int g = 0; g < G::GPC; ++g) {
+    const int off = g * 256 < cw ? (cb + g * 256 + lane * 4) * 4 : 0x7ffffff0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) w[g][r] = load_words(R.rsrc[r], off);
+  }
+
+  int thr_any = 0;  // wave-uniform: do any of this wave's rows hold threshold targets?
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    thr_any |= rowflags[rr[r] - row_begin];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      R.pi[r][d] = uniform(pos_in[(size_t)rr[r] * DIM + d]);  // wave-uniform: lives in SGPRs
+      R.acc[r][d] = 0;
+    }
+    const real g = (real)gplus[rr[r]];
+    R.ks[r] = uniform((real)(2.0 * k) / ((real)4 * g + (real)k));
+    R.cg[r] = uniform((real)(0.5 * c_rep) / g);
+  }
+  R.thr = ANYTHR && __builtin_amdgcn_readfirstlane(thr_any) != 0;
+  pipe_await_points<0>();
+  __syncthreads();
+
+  // one loop body for both halves of the double buffer (selected by address, not by unrolling:
+  // the prefetched words then stay in the same registers from one chunk to the next)
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    int ncb, ncw;
+    pipe_chunk_at<G::CHUNK>(rg, nc0, c + 1, ncb, ncw);
+    if (c + 1 >= nch) ncw = 0;
+    unsigned char* cur = bufs + (c & 1) * G::kBufBytes;
+    unsigned char* oth = bufs + ((c & 1) ^ 1) * G::kBufBytes;
+    if constexpr (CFG::UPFRONT == 3) {
+      // issue priority falls as a workgroup advances, so the workgroups sharing a CU finish
+      // together instead of oldest-first (the last one would otherwise run alone, latency-bound)
+      const int left = nch - c;
+      if (left >= 4) __builtin_amdgcn_s_setprio(0);
+      else if (left == 3) __builtin_amdgcn_s_setprio(1);
+      else if (left == 2) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(3);
+    }
+    pipe_chunk<DIM, real, CFG, ANYTHR>(R, pos_in, pos_bytes, cur, oth, cw, ncb, ncw, w, wave, lane);
+    cw = ncw;
+  }
+
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r;
+    bool finite = true;
+    real out[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const real total = wave_sum<real>(R.acc[r][d]);
+      out[d] = R.pi[r][d] - total;
+      finite = finite && isfinite(out[d]);
+    }
+    if (lane == 0 && row < row_end) {
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) pos_out[(size_t)row * DIM + d] = out[d];
+      if (!finite && st != nullptr) atomicMin(&st->first_nonfinite, iter1);
+    }
+  }
+  TL_WG_STAMP(1);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -195,12 +195,14 @@ struct ProfScope {
   }
 };
 
-// Stage-kernel geometry.  Production: 256 threads, 2 rows per wave (8 rows per workgroup),
-// 1024-column LDS chunks, register budget for 5 waves per SIMD -- the fastest of the variants
-// measured on MI355X.  A build with -DTOPOLOW_TUNING also instantiates the
-// other geometries and the ablation kernels, selectable with TOPOLOW_SLAB_VARIANT=<n>.
-using CfgProd = StageCfg<256, 2, 1024, 0, 0, 5>;
+// Stage-kernel geometry.  Production: the pipelined kernel (relax_kernels.h), 256 threads, 2 rows
+// per wave (8 rows per workgroup), register budget for 5 waves per SIMD -- the fastest of the
+// variants measured on MI355X.  A build with -DTOPOLOW_TUNING also
+// instantiates the barrier-staged kernel in several geometries and the ablation kernels,
+// selectable with TOPOLOW_SLAB_VARIANT=<n>.
+using CfgProd = StageCfg<256, 2, 0, 0, 0, 5>;   // CHUNK 0: PipeGeom picks it per dim
 #ifdef TOPOLOW_TUNING
+using CfgOld = StageCfg<256, 2, 1024, 0, 0, 5>; // barrier-staged kernel, production until the pipelined one
 using CfgA = StageCfg<256, 4, 1024>;            // 16 rows / WG
 using CfgB = StageCfg<512, 2, 1024>;            // 16 rows / WG, twice the waves
 using CfgC = StageCfg<512, 2, 2560>;            // whole 10k/4 slab in one LDS image
@@ -214,10 +216,38 @@ using CfgH = StageCfg<256, 2, 1024, 0, 2>;      // arithmetic only (results wron
 using CfgI = StageCfg<256, 2, 1024, 0, 0, 8>;   // squeezed to 64 VGPRs
 using CfgJ = StageCfg<256, 2, 1024, 0, 0, 6>;   // squeezed to 80 VGPRs
 
+// TOPOLOW_WG_STAMPS=<file>: the stage kernel's workgroups stamp their start/end times; the last
+// launch's stamps are written to <file> as text when the session is destroyed.
+struct WgStamps {
+  unsigned long long* dev = nullptr;
+  int blocks = 0;
+  void arm(int nblocks) {
+    if (dev != nullptr || getenv("TOPOLOW_WG_STAMPS") == nullptr) return;
+    blocks = nblocks;
+    if (hipMalloc(&dev, sizeof(unsigned long long) * 2 * nblocks) != hipSuccess) { dev = nullptr; return; }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamps), &dev, sizeof(dev));
+  }
+  void dump() {
+    if (dev == nullptr) return;
+    std::vector<unsigned long long> h(2 * (size_t)blocks);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(getenv("TOPOLOW_WG_STAMPS"), "w")) {
+      for (int b = 0; b < blocks; ++b) fprintf(f, "%llu %llu\n", h[2 * b], h[2 * b + 1]);
+      fclose(f);
+    }
+    unsigned long long* none = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamps), &none, sizeof(none));
+    (void)hipFree(dev);
+    dev = nullptr;
+  }
+};
+WgStamps g_stamps;
+
 int slab_variant() {
   static int v = [] {
     const char* e = getenv("TOPOLOW_SLAB_VARIANT");
-    return e ? atoi(e) : 10;
+    return e ? atoi(e) : -1;
   }();
   return v;
 }
@@ -241,13 +271,29 @@ void launch_stage_cfg(topolow_session* s, const void* pin, void* pout, RunState*
   else launch(&slab_stage_kernel<DIM, real, CFG, false>);
 }
 
+template <int DIM, typename real, typename CFG>
+void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState* st,
+                       SlabRanges rg, int iter1, double k) {
+  const int blocks = (s->rows() + CFG::ROWS - 1) / CFG::ROWS;
+#ifdef TOPOLOW_TUNING
+  g_stamps.arm(blocks);
+#endif
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), 0, s->stream, s->enc.p, s->ld,
+                       s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
+                       s->rowflags.p, st, rg, iter1, k, s->c_rep);
+  };
+  if (s->any_threshold) launch(&slab_stage_pipe_kernel<DIM, real, CFG, true>);
+  else launch(&slab_stage_pipe_kernel<DIM, real, CFG, false>);
+}
+
 template <int DIM>
 void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st, SlabRanges rg,
                   int iter1, double k) {
   if (s->rows() <= 0) return;
   ProfScope prof(s, &s->prof_stage);
   if (s->precision == TOPOLOW_PRECISION_F64) {
-    launch_stage_cfg<DIM, double, StageCfg<256, 2, 512>>(s, pin, pout, st, rg, iter1, k);
+    launch_stage_pipe<DIM, double, StageCfg<256, 2, 0>>(s, pin, pout, st, rg, iter1, k);
   } else {
 #ifdef TOPOLOW_TUNING
     switch (slab_variant()) {
@@ -263,10 +309,17 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
       case 7: launch_stage_cfg<DIM, float, CfgH>(s, pin, pout, st, rg, iter1, k); break;
       case 8: launch_stage_cfg<DIM, float, CfgI>(s, pin, pout, st, rg, iter1, k); break;
       case 9: launch_stage_cfg<DIM, float, CfgJ>(s, pin, pout, st, rg, iter1, k); break;
-      default: launch_stage_cfg<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k); break;
+      case 10: launch_stage_cfg<DIM, float, CfgOld>(s, pin, pout, st, rg, iter1, k); break;
+      case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 25: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 3, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
+      case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
+      case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 6>>(s, pin, pout, st, rg, iter1, k); break;
+      default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k); break;
     }
 #else
-    launch_stage_cfg<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k);
+    launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k);
 #endif
   }
   HIP_TRY(hipGetLastError());
@@ -586,6 +639,9 @@ void topolow_session_destroy(topolow_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+#ifdef TOPOLOW_TUNING
+  g_stamps.dump();
+#endif
   delete s;
 }
 

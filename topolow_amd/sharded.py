@@ -414,7 +414,7 @@ def _bench_replicas(args, rank, world, local, coll):
                                f"synthetic N={n}, 70% missing, ndim=5, k0=5, cooling=0.01, c_repulsion=0.01",
                    "n_points": n, "ndim": ndim, "schedule": "slab", "parallelism": f"replicas x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None, "kernel": "slab_stage_kernel<5,float>",
+                     "frac": achieved / 8000.0, "traffic": None, "kernel": "slab_stage_pipe_kernel<5,float>",
                      "avg_launch_us": stage_ms * 1e3 / launches, "note": "rank 0, per GPU"},
         "final_mae": res.final_mae,
     }
@@ -462,7 +462,7 @@ def _bench_sharded(args, rank, world, local, coll):
         "roofline": {"bound": "hbm", "achieved": bytes_iter_rank * kb / max(brk.stage_seconds, 1e-9) / 1e9,
                      "peak": 8000.0, "unit": "GB/s",
                      "frac": bytes_iter_rank * kb / max(brk.stage_seconds, 1e-9) / 1e9 / 8000.0,
-                     "traffic": None, "kernel": "slab_stage_kernel<3,float>",
+                     "traffic": None, "kernel": "slab_stage_pipe_kernel<3,float>",
                      "note": "rank 0: algorithmic bytes of its row block / synchronised stage time"},
         "breakdown_ms_per_iteration": {"stage": 1e3 * brk.stage_seconds / kb,
                                        "all_gather": 1e3 * brk.gather_seconds / kb,
