@@ -106,6 +106,13 @@ struct topolow_session {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  // Convergence checks run beside the next iteration (slab schedule, own stream, not profiling):
+  // the error pass and the controller go to `check_stream` and read the position buffer the
+  // iteration ended in, which the stage kernels leave alone (`held`) until the next check.
+  hipStream_t check_stream = nullptr;
+  hipEvent_t ev_iter_done = nullptr, ev_check_done = nullptr;
+  int held = -1;
+  bool serial_checks = false;   // TOPOLOW_SERIAL_CHECKS=1: keep every check on the main stream
 
   DevBuf<uint32_t> enc;
   DevBuf<float> gplus;
@@ -113,7 +120,7 @@ struct topolow_session {
   bool any_threshold = true;   // does any row of the block hold a ">" / "<" target?
   int schedule = TOPOLOW_SCHEDULE_SLAB;   // SLAB, or GS = exact tile Gauss-Seidel (relax_tilegs.h)
   DevBuf<int> bperm;
-  DevBuf<unsigned char> pos[2];
+  DevBuf<unsigned char> pos[3];   // stage ping-pong + the buffer a running check reads
   DevBuf<unsigned char> best;
   DevBuf<int> ei, ej;
   DevBuf<unsigned char> et;
@@ -156,6 +163,9 @@ struct topolow_session {
     for (hipEvent_t e : pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (mailbox) (void)hipHostFree(mailbox);
+    if (ev_iter_done) (void)hipEventDestroy(ev_iter_done);
+    if (ev_check_done) (void)hipEventDestroy(ev_check_done);
+    if (check_stream) (void)hipStreamDestroy(check_stream);
     if (own_stream) (void)hipStreamDestroy(own_stream);
   }
 };
@@ -464,6 +474,14 @@ void poll_checks(topolow_session* s, size_t keep_in_flight) {
   }
 }
 
+// Launch helpers take the stream from the session: run a few of them on another one.
+struct StreamScope {
+  topolow_session* s;
+  hipStream_t saved;
+  StreamScope(topolow_session* s_, hipStream_t on) : s(s_), saved(s_->stream) { s->stream = on; }
+  ~StreamScope() { s->stream = saved; }
+};
+
 // ---- exact tile Gauss-Seidel iteration (relax_tilegs.h): in place on `pos` -------------------
 template <int DIM>
 void launch_tilegs_iteration(topolow_session* s, void* pos, int iter, double k) {
@@ -620,10 +638,14 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
                                                       : TOPOLOW_PRECISION_F32;
     HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     s->stream = s->own_stream;
+    HIP_TRY(hipStreamCreateWithFlags(&s->check_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_iter_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_check_done, hipEventDisableTiming));
+    const char* serial = getenv("TOPOLOW_SERIAL_CHECKS");
+    s->serial_checks = serial != nullptr && serial[0] == '1';
     s->enc.alloc((size_t)s->rows() * s->ld);
     const size_t pos_bytes = (size_t)s->pos_rows() * ndim * s->real_size();
-    s->pos[0].alloc(pos_bytes);
-    s->pos[1].alloc(pos_bytes);
+    for (auto& b : s->pos) b.alloc(pos_bytes);
     s->best.alloc(pos_bytes);
     s->state.alloc(1);
     HIP_TRY(hipHostMalloc((void**)&s->mailbox, sizeof(RunState), hipHostMallocMapped));
@@ -639,6 +661,7 @@ void topolow_session_destroy(topolow_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->check_stream) (void)hipStreamSynchronize(s->check_stream);
 #ifdef TOPOLOW_TUNING
   g_stamps.dump();
 #endif
@@ -798,9 +821,11 @@ int topolow_session_set_positions(topolow_session* s, const double* positions, c
     HIP_TRY(hipSetDevice(s->device));
     s->cur = 0;
     upload_positions(s, positions, s->pos[0].p);
-    // the other ping-pong buffer needs the same padding rows
-    HIP_TRY(hipMemcpy(s->pos[1].p, s->pos[0].p, (size_t)s->pos_rows() * s->dim * s->real_size(),
-                      hipMemcpyDeviceToDevice));
+    // the other buffers need the same padding rows
+    for (int b = 1; b < 3; ++b)
+      HIP_TRY(hipMemcpy(s->pos[b].p, s->pos[0].p, (size_t)s->pos_rows() * s->dim * s->real_size(),
+                        hipMemcpyDeviceToDevice));
+    s->held = -1;
   });
 }
 
@@ -823,6 +848,7 @@ int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double 
     if (!s->gplus.p) throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "session has no targets loaded"};
     if (!s->part_sum.p) throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "session has no edge list"};
     HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->check_stream));
     for (hipEvent_t e : s->pending) s->event_pool.push_back(e);
     s->pending.clear();
     s->n_iter = n_iter;
@@ -837,6 +863,7 @@ int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double 
     s->iters_enqueued = 0;
     s->k_host = k0;
     s->host_seen_stop = false;
+    s->held = -1;
     s->began = true;
     RunState st;
     std::memset(&st, 0, sizeof st);
@@ -871,22 +898,43 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         const SlabGeom g = slab_geom(s->n, stages);
         for (int slot = 0; slot < g.n_stages; ++slot) {
           const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
-          TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[s->cur].p, s->pos[s->cur ^ 1].p,
-                          s->state.p, rg, iter + 1, s->k_host);
-          s->cur ^= 1;
+          int out = 0;   // a buffer that is neither the input nor the one a running check reads
+          while (out == s->cur || out == s->held) ++out;
+          TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[s->cur].p, s->pos[out].p, s->state.p, rg,
+                          iter + 1, s->k_host);
+          s->cur = out;
         }
       }
       s->iters_enqueued = iter + 1;
       s->k_host *= (1.0 - s->cooling);  // reference :289
       ++done;
       if ((iter + 1) % s->check_freq == 0 || iter == s->n_iter - 1) {  // reference :294
+        const bool beside = s->schedule == TOPOLOW_SCHEDULE_SLAB && s->stream == s->own_stream &&
+                            !s->profiling && !s->serial_checks;
+        hipStream_t check_on = s->stream;
+        if (beside) {
+          // The check reads this iteration's positions while the next iteration's stages run.  Its
+          // verdict (stop / snapshot) is the same as in the serial order: the buffer it reads is
+          // not written until the next check has waited for it; stage kernels that start after a
+          // stop are no-ops and those already running write buffers nobody returns.
+          if (s->held >= 0) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_check_done, 0));
+          s->held = s->cur;
+          HIP_TRY(hipEventRecord(s->ev_iter_done, s->stream));
+          HIP_TRY(hipStreamWaitEvent(s->check_stream, s->ev_iter_done, 0));
+          check_on = s->check_stream;
+        } else if (s->held >= 0) {
+          HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_check_done, 0));
+          s->held = -1;
+        }
         {
+          StreamScope on(s, check_on);
           ProfScope prof(s, &s->prof_check);
           TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[s->cur].p, s->state.p);
           launch_controller(s, s->pos[s->cur].p, iter + 1, s->k_host);
         }
+        if (beside) HIP_TRY(hipEventRecord(s->ev_check_done, check_on));
         hipEvent_t e = take_event(s);
-        HIP_TRY(hipEventRecord(e, s->stream));
+        HIP_TRY(hipEventRecord(e, check_on));
         s->pending.push_back(e);
         poll_checks(s, 3);
       }
@@ -905,6 +953,7 @@ int topolow_session_sync(topolow_session* s, int32_t* iterations_run, int32_t* s
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->check_stream));
     poll_checks(s, 0);
     RunState st;
     HIP_TRY(hipMemcpy(&st, s->state.p, sizeof st, hipMemcpyDeviceToHost));
@@ -923,6 +972,7 @@ int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* c
   const int rc = guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->check_stream));
     poll_checks(s, 0);
     RunState st;
     HIP_TRY(hipMemcpy(&st, s->state.p, sizeof st, hipMemcpyDeviceToHost));
@@ -959,6 +1009,7 @@ int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->check_stream));
     auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double* ms, int64_t* cnt) {
       double total = 0.0;
       for (auto& pr : v) {
@@ -980,6 +1031,7 @@ int topolow_session_set_stream(topolow_session* s, void* hip_stream, int32_t ext
   if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
+  (void)hipStreamSynchronize(s->check_stream);
   s->stream = external ? (hipStream_t)hip_stream : s->own_stream;
   return TOPOLOW_OK;
 }
