@@ -396,13 +396,112 @@ __device__ __forceinline__ void pipe_await_points() {
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kYounger) : "memory");
 }
 
-template <int DIM, typename real, int RPW, bool ANYTHR>
+// The rows a wave moves: coordinates and row constants (wave-uniform), accumulators, target rows.
+// Generic form: one scalar pair update per (row, column).
+template <int DIM, typename real, int RPW, bool ANYTHR, bool PACKED = (sizeof(real) == 4 && RPW == 2)>
 struct PipeRows {
   real pi[RPW][DIM];
   real acc[RPW][DIM];
   real ks[RPW], cg[RPW];
   row_rsrc_t rsrc[RPW];
   bool thr;
+
+  __device__ __forceinline__ void set_row(int r, const real (&p)[DIM], real ks_r, real cg_r) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { pi[r][d] = p[d]; acc[r][d] = 0; }
+    ks[r] = ks_r;
+    cg[r] = cg_r;
+  }
+  // four column points against every row; w[r] = the rows' target words of those columns
+  __device__ __forceinline__ void group(const real (&pc)[4][DIM], const uint4 (&w)[RPW]) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      if (ANYTHR && thr) {
+        pair_accum<DIM, real, true>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, true>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, true>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, true>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r]);
+      } else {
+        pair_accum<DIM, real, false>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, false>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, false>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, false>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r]);
+      }
+    }
+  }
+  __device__ __forceinline__ real origin(int r, int d) const { return pi[r][d]; }
+  __device__ __forceinline__ real lane_sum(int r, int d) const { return acc[r][d]; }
+};
+
+// fp32, two rows per wave: the two rows ride in the two halves of packed fp32 operations
+// (v_pk_add/mul/fma_f32) -- the column point is broadcast, the rows' coordinates and constants are
+// scalar-register pairs, the accumulators are register pairs -- so every non-transcendental
+// operation of a column serves both rows.  Same operations in the same order per row as the
+// generic form (bit-identical results).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+template <int DIM, bool THR>
+__device__ __forceinline__ void pair_accum_rows2(const float (&pc)[DIM], const f32x2_t (&pi2)[DIM],
+                                                 uint32_t w0, uint32_t w1, f32x2_t ks2, f32x2_t cg2,
+                                                 f32x2_t (&acc2)[DIM]) {
+  f32x2_t dx[DIM];
+  f32x2_t s = {0.0f, 0.0f};
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const f32x2_t pcd = {pc[d], pc[d]};
+    dx[d] = pcd - pi2[d];
+    s = __builtin_elementwise_fma(dx[d], dx[d], s);
+  }
+  const f32x2_t r = {Math<float>::sqrt(s.x), Math<float>::sqrt(s.y)};
+  const f32x2_t rs = r + (f32x2_t){0.01f, 0.01f};
+  const f32x2_t inv = {Math<float>::rcp(rs.x), Math<float>::rcp(rs.y)};
+  const f32x2_t t = {bits_f32(THR ? (w0 & ~kCodeMask) : w0), bits_f32(THR ? (w1 & ~kCodeMask) : w1)};
+  bool sp0, sp1;
+  if constexpr (THR) {
+    const uint32_t c0 = w0 & kCodeMask, c1 = w1 & kCodeMask;
+    sp0 = (c0 == 0u) | ((c0 == 1u) & (r.x < t.x)) | ((c0 == 2u) & (r.x > t.x));
+    sp1 = (c1 == 0u) | ((c1 == 1u) & (r.y < t.y)) | ((c1 == 2u) & (r.y > t.y));
+  } else {
+    sp0 = __builtin_amdgcn_classf(bits_f32(w0), 0x1f8);
+    sp1 = __builtin_amdgcn_classf(bits_f32(w1), 0x1f8);
+  }
+  const f32x2_t fs = (t - r) * inv * ks2;
+  const f32x2_t fr = inv * inv * inv * cg2;
+  const f32x2_t coef = {sp0 ? fs.x : fr.x, sp1 ? fs.y : fr.y};
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) acc2[d] = __builtin_elementwise_fma(dx[d], coef, acc2[d]);
+}
+
+template <int DIM, bool ANYTHR>
+struct PipeRows<DIM, float, 2, ANYTHR, true> {
+  f32x2_t pi2[DIM];    // (row 0, row 1) per coordinate
+  f32x2_t acc2[DIM];
+  f32x2_t ks2, cg2;
+  row_rsrc_t rsrc[2];
+  bool thr;
+
+  __device__ __forceinline__ void set_row(int r, const float (&p)[DIM], float ks_r, float cg_r) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      if (r == 0) { pi2[d].x = p[d]; acc2[d].x = 0; } else { pi2[d].y = p[d]; acc2[d].y = 0; }
+    }
+    if (r == 0) { ks2.x = ks_r; cg2.x = cg_r; } else { ks2.y = ks_r; cg2.y = cg_r; }
+  }
+  __device__ __forceinline__ void group(const float (&pc)[4][DIM], const uint4 (&w)[2]) {
+    if (ANYTHR && thr) {
+      pair_accum_rows2<DIM, true>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, true>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, true>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, true>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2);
+    } else {
+      pair_accum_rows2<DIM, false>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, false>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, false>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, false>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2);
+    }
+  }
+  __device__ __forceinline__ float origin(int r, int d) const { return r == 0 ? pi2[d].x : pi2[d].y; }
+  __device__ __forceinline__ float lane_sum(int r, int d) const { return r == 0 ? acc2[d].x : acc2[d].y; }
 };
 
 // One chunk: request the next chunk's points into `oth`, sweep this chunk's groups out of `cur`.
@@ -425,20 +524,7 @@ __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>
     if (c4 < cw) {
       real pc[4][DIM];
       load_points<DIM, real>(lds_pos, c4, pc);
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        if (ANYTHR && R.thr) {
-          pair_accum<DIM, real, true>(pc[0], R.pi[r], w[g][r].x, R.ks[r], R.cg[r], R.acc[r]);
-          pair_accum<DIM, real, true>(pc[1], R.pi[r], w[g][r].y, R.ks[r], R.cg[r], R.acc[r]);
-          pair_accum<DIM, real, true>(pc[2], R.pi[r], w[g][r].z, R.ks[r], R.cg[r], R.acc[r]);
-          pair_accum<DIM, real, true>(pc[3], R.pi[r], w[g][r].w, R.ks[r], R.cg[r], R.acc[r]);
-        } else {
-          pair_accum<DIM, real, false>(pc[0], R.pi[r], w[g][r].x, R.ks[r], R.cg[r], R.acc[r]);
-          pair_accum<DIM, real, false>(pc[1], R.pi[r], w[g][r].y, R.ks[r], R.cg[r], R.acc[r]);
-          pair_accum<DIM, real, false>(pc[2], R.pi[r], w[g][r].z, R.ks[r], R.cg[r], R.acc[r]);
-          pair_accum<DIM, real, false>(pc[3], R.pi[r], w[g][r].w, R.ks[r], R.cg[r], R.acc[r]);
-        }
-      }
+      R.group(pc, w[g]);
     }
     // The same group of the next chunk, requested as soon as this group's words are dead (so they
     // land in the same registers).  Unconditional: the count of loads per chunk is what
@@ -496,14 +582,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     thr_any |= rowflags[rr[r] - row_begin];
+    real p[DIM];
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      R.pi[r][d] = uniform(pos_in[(size_t)rr[r] * DIM + d]);  // wave-uniform: lives in SGPRs
-      R.acc[r][d] = 0;
-    }
+    for (int d = 0; d < DIM; ++d) p[d] = uniform(pos_in[(size_t)rr[r] * DIM + d]);  // scalar registers
     const real g = (real)gplus[rr[r]];
-    R.ks[r] = uniform((real)(2.0 * k) / ((real)4 * g + (real)k));
-    R.cg[r] = uniform((real)(0.5 * c_rep) / g);
+    R.set_row(r, p, uniform((real)(2.0 * k) / ((real)4 * g + (real)k)), uniform((real)(0.5 * c_rep) / g));
   }
   R.thr = ANYTHR && __builtin_amdgcn_readfirstlane(thr_any) != 0;
   pipe_await_points<0>();
@@ -538,8 +621,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
     real out[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
-      const real total = wave_sum<real>(R.acc[r][d]);
-      out[d] = R.pi[r][d] - total;
+      const real total = wave_sum<real>(R.lane_sum(r, d));
+      out[d] = R.origin(r, d) - total;
       finite = finite && isfinite(out[d]);
     }
     if (lane == 0 && row < row_end) {

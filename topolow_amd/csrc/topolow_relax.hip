@@ -322,6 +322,7 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
       case 10: launch_stage_cfg<DIM, float, CfgOld>(s, pin, pout, st, rg, iter1, k); break;
       case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
       case 25: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 3, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 26: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
       case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
       case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
       case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
