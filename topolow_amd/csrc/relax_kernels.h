@@ -668,6 +668,38 @@ __device__ __forceinline__ void pair_error(const real (&pc)[DIM], const real (&p
   cnt += contributes ? 1u : 0u;
 }
 
+// fp32, two rows per wave, every pair of the batch counted (tile right of the diagonal): the two
+// rows ride in the halves of packed fp32 operations, as in the stage kernel.  Same operations per
+// pair as pair_error; the count goes through the scalar unit (population count of the lane mask).
+template <int DIM, bool THR>
+__device__ __forceinline__ void pair_error_rows2(const float (&pc)[DIM], const f32x2_t (&pi2)[DIM],
+                                                 uint32_t w0, uint32_t w1, float& err,
+                                                 unsigned& cnt_wave) {
+  f32x2_t s = {0.0f, 0.0f};
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const f32x2_t pcd = {pc[d], pc[d]};
+    const f32x2_t dx = pcd - pi2[d];
+    s = __builtin_elementwise_fma(dx, dx, s);
+  }
+  const f32x2_t r = {Math<float>::sqrt(s.x), Math<float>::sqrt(s.y)};
+  const f32x2_t t = {bits_f32(THR ? (w0 & ~kCodeMask) : w0), bits_f32(THR ? (w1 & ~kCodeMask) : w1)};
+  const f32x2_t e = t - r;
+  bool c0, c1;
+  if constexpr (THR) {
+    const uint32_t k0 = w0 & kCodeMask, k1 = w1 & kCodeMask;
+    c0 = (k0 == 0u) | ((k0 == 1u) & (r.x < t.x)) | ((k0 == 2u) & (r.x > t.x));
+    c1 = (k1 == 0u) | ((k1 == 1u) & (r.y < t.y)) | ((k1 == 2u) & (r.y > t.y));
+  } else {
+    c0 = __builtin_amdgcn_classf(bits_f32(w0), 0x1f8);
+    c1 = __builtin_amdgcn_classf(bits_f32(w1), 0x1f8);
+  }
+  err += fabsf(c0 ? e.x : 0.0f);
+  err += fabsf(c1 ? e.y : 0.0f);
+  cnt_wave += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c0)) +
+              (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c1));
+}
+
 // Grid: x = column chunk (CFG::CHUNK columns), y = row tile (kErrTileRows rows).  A workgroup stages
 // its chunk's points into LDS ONCE and sweeps the tile's rows over it (RPW rows per wave at a
 // time), so the staging is amortised over kErrTileRows rows; tiles that hold no pair to reduce
@@ -739,6 +771,38 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
       for (int r = 0; r < RPW; ++r) {
         const bool need = c4 < cw && (PARITY || cb + c4 + 3 > rows[r]) && rows[r] != 0x7fffffff;
         w4[t][r] = need ? load_words(rsrc[r], (cb + c4) * 4) : make_uint4(kInfWord, kInfWord, kInfWord, kInfWord);
+      }
+    }
+    if constexpr (sizeof(real) == 4 && RPW == 2 && !PARITY) {
+      // both rows valid and the whole chunk right of them: every pair of the batch is counted
+      if (row0 + 1 < row_end && cb > row0 + 1) {     // wave-uniform
+        f32x2_t pi2[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) pi2[d] = (f32x2_t){pi[0][d], pi[1][d]};
+        unsigned cnt_wave = 0;
+#pragma unroll
+        for (int t = 0; t < kGroups; ++t) {
+          const int c4 = lane * 4 + t * 256;
+          if (c4 < cw) {
+            real pc[4][DIM];
+            load_points<DIM, real>(lds_pos, c4, pc);
+            if (thr) {
+              pair_error_rows2<DIM, true>(pc[0], pi2, w4[t][0].x, w4[t][1].x, err, cnt_wave);
+              pair_error_rows2<DIM, true>(pc[1], pi2, w4[t][0].y, w4[t][1].y, err, cnt_wave);
+              pair_error_rows2<DIM, true>(pc[2], pi2, w4[t][0].z, w4[t][1].z, err, cnt_wave);
+              pair_error_rows2<DIM, true>(pc[3], pi2, w4[t][0].w, w4[t][1].w, err, cnt_wave);
+            } else {
+              pair_error_rows2<DIM, false>(pc[0], pi2, w4[t][0].x, w4[t][1].x, err, cnt_wave);
+              pair_error_rows2<DIM, false>(pc[1], pi2, w4[t][0].y, w4[t][1].y, err, cnt_wave);
+              pair_error_rows2<DIM, false>(pc[2], pi2, w4[t][0].z, w4[t][1].z, err, cnt_wave);
+              pair_error_rows2<DIM, false>(pc[3], pi2, w4[t][0].w, w4[t][1].w, err, cnt_wave);
+            }
+          }
+        }
+        if (lane == 0) cnt += cnt_wave;   // the wave's count rides in lane 0's counter
+        err_d += (double)err;
+        err = 0.0f;
+        continue;
       }
     }
 #pragma unroll
