@@ -235,6 +235,32 @@ def test_coo_load_equals_dense_load():
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_checks_beside_next_iteration_change_nothing(monkeypatch):
+    """The convergence check runs on a second stream beside the next iteration's stages (single
+    GPU, slab schedule); TOPOLOW_SERIAL_CHECKS=1 keeps it on the main stream.  Same verdicts, same
+    snapshot: converged runs (the stop arrives while later stages are already queued or running),
+    check_freq 1 (a check every iteration) and an exhausted run must all be identical."""
+    call, _ = _random_problem(700, 3, 0.6, seed=31, thresholds=0.1, n_iter=400, k0=6.0, cool=0.03, c_rep=0.01)
+    outs = {}
+    for serial in ("1", "0"):
+        monkeypatch.setenv("TOPOLOW_SERIAL_CHECKS", serial)
+        rows = []
+        for n_iter, window, freq in ((400, 3, 3), (400, 2, 1), (7, 5, 2)):
+            s = _native.Session(700, 3, precision="f32")
+            s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+            s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+            s.set_positions(call.initial_positions)
+            s.begin(n_iter, 6.0, 0.03, 0.01, 1e-3, window, freq, 5, 0)
+            s.run()
+            r = s.finish()
+            rows.append((r.positions.copy(), r.converged, r.iterations, r.final_mae, r.final_k))
+            s.close()
+        outs[serial] = rows
+    assert outs["1"][0][1] and outs["1"][1][1] and not outs["1"][2][1]     # two stops, one exhausted run
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+
+
 # ----------------------------------------------------------------------------------------
 # slab schedule end-to-end vs the reference schedule (statistical), plus post metrics
 # ----------------------------------------------------------------------------------------

@@ -23,7 +23,8 @@ constexpr int kWaves = kThreads / 64;
 //   THREADS : workgroup size (waves share one LDS image of the slab's column points)
 //   RPW     : rows (points being moved) per wave; their coordinates sit in SGPRs
 //   CHUNK   : slab columns staged in LDS at a time (multiple of 256)
-//   UPFRONT : 1 = request a whole chunk's target words right after the staging barrier
+//   UPFRONT : barrier-staged kernel: 1 = request a whole chunk's target words right after the
+//             staging barrier; pipelined kernel: 3 = issue priority falls as the workgroup advances
 //   ABLATE  : tuning builds only -- 1 = skip the pair arithmetic (memory floor), 2 = skip the
 //             target loads (arithmetic floor); results are wrong on purpose
 //   MINWAVES: second __launch_bounds__ argument (waves per SIMD the register budget must allow)
@@ -605,10 +606,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
       // issue priority falls as a workgroup advances, so the workgroups sharing a CU finish
       // together instead of oldest-first (the last one would otherwise run alone, latency-bound)
       const int left = nch - c;
-      if (left >= 4) __builtin_amdgcn_s_setprio(0);
-      else if (left == 3) __builtin_amdgcn_s_setprio(1);
-      else if (left == 2) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(3);
+      if (left >= 4) __builtin_amdgcn_s_setprio(3);
+      else if (left == 3) __builtin_amdgcn_s_setprio(2);
+      else if (left == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
     }
     pipe_chunk<DIM, real, CFG, ANYTHR>(R, pos_in, pos_bytes, cur, oth, cw, ncb, ncw, w, wave, lane);
     cw = ncw;

@@ -210,7 +210,7 @@ struct ProfScope {
 // variants measured on MI355X.  A build with -DTOPOLOW_TUNING also
 // instantiates the barrier-staged kernel in several geometries and the ablation kernels,
 // selectable with TOPOLOW_SLAB_VARIANT=<n>.
-using CfgProd = StageCfg<256, 2, 0, 0, 0, 5>;   // CHUNK 0: PipeGeom picks it per dim
+using CfgProd = StageCfg<256, 2, 0, 3, 0, 5>;   // CHUNK 0: PipeGeom picks it per dim; 3: falling priority
 #ifdef TOPOLOW_TUNING
 using CfgOld = StageCfg<256, 2, 1024, 0, 0, 5>; // barrier-staged kernel, production until the pipelined one
 using CfgA = StageCfg<256, 4, 1024>;            // 16 rows / WG
@@ -321,7 +321,7 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
       case 9: launch_stage_cfg<DIM, float, CfgJ>(s, pin, pout, st, rg, iter1, k); break;
       case 10: launch_stage_cfg<DIM, float, CfgOld>(s, pin, pout, st, rg, iter1, k); break;
       case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 25: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 3, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 25: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
       case 26: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
       case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
       case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
