@@ -19,20 +19,17 @@ namespace topolow {
 constexpr int kThreads = 256;       // block size of the auxiliary kernels
 constexpr int kWaves = kThreads / 64;
 
-// Launch geometry of the slab stage kernel.
+// Launch geometry of the slab stage kernel (and of the dense error pass, which shares its tiling).
 //   THREADS : workgroup size (waves share one LDS image of the slab's column points)
-//   RPW     : rows (points being moved) per wave; their coordinates sit in SGPRs
-//   CHUNK   : slab columns staged in LDS at a time (multiple of 256)
-//   UPFRONT : barrier-staged kernel: 1 = request a whole chunk's target words right after the
-//             staging barrier; pipelined kernel: 3 = issue priority falls as the workgroup advances
-//   ABLATE  : tuning builds only -- 1 = skip the pair arithmetic (memory floor), 2 = skip the
-//             target loads (arithmetic floor); results are wrong on purpose
+//   RPW     : rows (points being moved) per wave; their coordinates sit in scalar registers
+//   CHUNK   : slab columns per LDS buffer (multiple of 256); stage kernel: 0 = as many 256-column
+//             groups as keep its double buffer near 20 KB (PipeGeom)
+//   PRIO    : stage kernel: 1 = issue priority falls as the workgroup advances through its slab
 //   MINWAVES: second __launch_bounds__ argument (waves per SIMD the register budget must allow)
-template <int THREADS_, int RPW_, int CHUNK_, int UPFRONT_ = 0, int ABLATE_ = 0, int MINWAVES_ = 1>
+template <int THREADS_, int RPW_, int CHUNK_, int PRIO_ = 0, int MINWAVES_ = 1>
 struct StageCfg {
   static constexpr int MINWAVES = MINWAVES_;
-  static constexpr int UPFRONT = UPFRONT_;
-  static constexpr int ABLATE = ABLATE_;
+  static constexpr int PRIO = PRIO_;
   static constexpr int THREADS = THREADS_;
   static constexpr int WAVES = THREADS_ / 64;
   static constexpr int RPW = RPW_;
@@ -166,159 +163,6 @@ __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&p
   for (int d = 0; d < DIM; ++d) acc[d] = fma(dx[d], coef, acc[d]);
 }
 
-// One slab stage for rows [row_begin,row_end).
-//   denc    : (row_end-row_begin) x ld encoded targets, row-major, ld % 64 == 0
-//   pos_in  : n x DIM row-major, all points, read-only in this launch
-//   pos_out : n x DIM row-major; rows [row_begin,row_end) are written
-//   st      : run state (nullable): launch is a no-op once st->stopped is set; non-finite
-//             results are reported through st->first_nonfinite
-//   ANYTHR = false: the host has checked that NO row of the block holds a threshold target,
-//   so only the cheaper classification is compiled in (fewer registers, one more wave per SIMD).
-template <int DIM, typename real, typename CFG, bool ANYTHR>
-__global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_kernel(
-    const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
-    const real* __restrict__ pos_in, real* __restrict__ pos_out,
-    const float* __restrict__ gplus, const unsigned char* __restrict__ rowflags, RunState* st,
-    SlabRanges rg, int iter1, double k, double c_rep) {
-  if (st != nullptr && st->stopped) return;
-
-  constexpr int kChunk = CFG::CHUNK;
-  constexpr int RPW = CFG::RPW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char slab_smem[];
-  real* lds_pos = reinterpret_cast<real*>(slab_smem);  // [DIM][kChunk]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = row_begin + blockIdx.x * CFG::ROWS + wave * RPW;
-
-  real pi[RPW][DIM];
-  real acc[RPW][DIM];
-  real ks[RPW], cg[RPW];
-  const uint32_t* rowp[RPW];
-  int thr_any = 0;  // wave-uniform: do any of this wave's rows hold threshold targets?
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int row = row0 + r;
-    const int rr = row < row_end ? row : row_end - 1;  // clamp: result discarded below
-    thr_any |= rowflags[rr - row_begin];
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      pi[r][d] = uniform(pos_in[(size_t)rr * DIM + d]);  // wave-uniform: lives in SGPRs
-      acc[r][d] = 0;
-    }
-    const real g = (real)gplus[rr];
-    ks[r] = uniform((real)(2.0 * k) / ((real)4 * g + (real)k));
-    cg[r] = uniform((real)(0.5 * c_rep) / g);
-    rowp[r] = denc + (size_t)(rr - row_begin) * ld;
-  }
-  row_rsrc_t rsrc[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) rsrc[r] = make_row_rsrc(rowp[r], ld);
-  const bool thr = ANYTHR && __builtin_amdgcn_readfirstlane(thr_any) != 0;
-
-#pragma unroll 1
-  for (int part = 0; part < 2; ++part) {
-    const int rb = part == 0 ? rg.b0 : rg.b1;
-    const int re = part == 0 ? rg.e0 : rg.e1;
-#pragma unroll 1
-    for (int cb = rb; cb < re; cb += kChunk) {
-      const int cw = min(kChunk, re - cb);  // multiple of 4
-      __syncthreads();  // previous chunk fully consumed
-      stage_points<DIM, real, CFG::THREADS, kChunk>(pos_in, cb, cw, lds_pos, tid);
-      __syncthreads();
-      if constexpr (CFG::UPFRONT == 1) {
-        // all target words of the chunk are requested right after the staging barrier, then
-        // consumed group by group (one exposed latency per chunk instead of one per group)
-        constexpr int kGroups = kChunk / 256;
-        uint4 wa[kGroups][RPW];
-#pragma unroll
-        for (int t = 0; t < kGroups; ++t) {
-          const int c4 = lane * 4 + t * 256;
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-            wa[t][r] = c4 < cw ? load_words(rsrc[r], (cb + c4) * 4)
-                               : make_uint4(kInfWord, kInfWord, kInfWord, kInfWord);
-        }
-#pragma unroll
-        for (int t = 0; t < kGroups; ++t) {
-          const int c4 = lane * 4 + t * 256;
-          if (c4 >= cw) continue;
-          real pc[4][DIM];
-          load_points<DIM, real>(lds_pos, c4, pc);
-#pragma unroll
-          for (int r = 0; r < RPW; ++r) {
-            if (ANYTHR && thr) {
-              pair_accum<DIM, real, true>(pc[0], pi[r], wa[t][r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[1], pi[r], wa[t][r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[2], pi[r], wa[t][r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, true>(pc[3], pi[r], wa[t][r].w, ks[r], cg[r], acc[r]);
-            } else {
-              pair_accum<DIM, real, false>(pc[0], pi[r], wa[t][r].x, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[1], pi[r], wa[t][r].y, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[2], pi[r], wa[t][r].z, ks[r], cg[r], acc[r]);
-              pair_accum<DIM, real, false>(pc[3], pi[r], wa[t][r].w, ks[r], cg[r], acc[r]);
-            }
-          }
-        }
-      } else
-#pragma unroll 1
-      for (int c4 = lane * 4; c4 < cw; c4 += 256) {
-        uint4 w4[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-          if constexpr (CFG::ABLATE == 2) {
-            w4[r] = make_uint4(0x40000000u + c4, 0x40400002u, 0x7f800002u, 0x40800001u);
-          } else {
-            // buffer load: per-row descriptor in SGPRs + one shared 32-bit lane offset
-            w4[r] = load_words(rsrc[r], (cb + c4) * 4);
-          }
-        }
-        if constexpr (CFG::ABLATE == 1) {
-#pragma unroll
-          for (int r = 0; r < RPW; ++r)
-            acc[r][0] += (float)((w4[r].x ^ w4[r].y ^ w4[r].z ^ w4[r].w) & 1u) * 1e-30f;
-          continue;
-        }
-        real pc[4][DIM];
-        load_points<DIM, real>(lds_pos, c4, pc);
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-          if (ANYTHR && thr) {
-            pair_accum<DIM, real, true>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
-            pair_accum<DIM, real, true>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
-            pair_accum<DIM, real, true>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
-            pair_accum<DIM, real, true>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
-          } else {
-            pair_accum<DIM, real, false>(pc[0], pi[r], w4[r].x, ks[r], cg[r], acc[r]);
-            pair_accum<DIM, real, false>(pc[1], pi[r], w4[r].y, ks[r], cg[r], acc[r]);
-            pair_accum<DIM, real, false>(pc[2], pi[r], w4[r].z, ks[r], cg[r], acc[r]);
-            pair_accum<DIM, real, false>(pc[3], pi[r], w4[r].w, ks[r], cg[r], acc[r]);
-          }
-        }
-      }
-    }
-  }
-
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int row = row0 + r;
-    bool finite = true;
-    real out[DIM];
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      const real total = wave_sum<real>(acc[r][d]);
-      out[d] = pi[r][d] - total;
-      finite = finite && isfinite(out[d]);
-    }
-    if (lane == 0 && row < row_end) {
-#pragma unroll
-      for (int d = 0; d < DIM; ++d) pos_out[(size_t)row * DIM + d] = out[d];
-      if (!finite && st != nullptr) atomicMin(&st->first_nonfinite, iter1);
-    }
-  }
-}
-
 #ifdef TOPOLOW_TUNING
 // Tuning builds: per-workgroup start/end stamps (100 MHz constant clock) of the stage kernel's last
 // launch, for the dispatch-ramp / tail analysis in DESIGN.md section 6.
@@ -330,9 +174,8 @@ __device__ unsigned long long* g_wg_stamps = nullptr;
 #endif
 
 // ----------------------------------------------------------------------------------------
-// Pipelined form of the stage kernel (the production one).  Same arithmetic and the same
-// summation order as slab_stage_kernel -- lane l of a wave takes columns 4l..4l+3 of every
-// 256-column group, groups in slab order -- but nothing in the steady state waits for memory:
+// The stage kernel.  Lane l of a wave takes columns 4l..4l+3 of every 256-column group, groups in
+// slab order; nothing in the steady state waits for memory:
 //   * the slab's column points move HBM/L2 -> LDS with direct-to-LDS loads (no registers), one
 //     chunk ahead, into the other half of a double buffer: one barrier per chunk, no exposed
 //     staging;
@@ -384,8 +227,11 @@ __device__ __forceinline__ void pipe_request_points(const real* __restrict__ pos
       // Written as asm on purpose: hipcc drains vmcnt to 0 at every barrier while it knows of an
       // LDS transfer in flight, which would also drain the target-word prefetch.  The wave that
       // issues a transfer awaits it itself (pipe_await_points) before the barrier.
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                   :: "v"(src + off), "s"(lds_dst) : "memory", "m0");
+      // (m0 holds the LDS address of the transfer; it is put back, the backend treats it as its own)
+      unsigned saved_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(saved_m0) : "v"(src + off), "s"(lds_dst) : "memory");
     }
   }
 }
@@ -539,6 +385,14 @@ __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>
   __syncthreads();   // next chunk's points have landed; every wave is done reading `cur`
 }
 
+// One slab stage for rows [row_begin,row_end).
+//   denc    : (row_end-row_begin) x ld encoded targets, row-major, ld % 64 == 0
+//   pos_in  : n x DIM row-major, all points, read-only in this launch
+//   pos_out : n x DIM row-major; rows [row_begin,row_end) are written
+//   st      : run state (nullable): launch is a no-op once st->stopped is set; non-finite
+//             results are reported through st->first_nonfinite
+//   ANYTHR = false: the host has checked that NO row of the block holds a threshold target,
+//   so only the cheaper classification is compiled in (fewer registers, one more wave per SIMD).
 template <int DIM, typename real, typename CFG, bool ANYTHR>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_kernel(
     const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
@@ -602,7 +456,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
     if (c + 1 >= nch) ncw = 0;
     unsigned char* cur = bufs + (c & 1) * G::kBufBytes;
     unsigned char* oth = bufs + ((c & 1) ^ 1) * G::kBufBytes;
-    if constexpr (CFG::UPFRONT == 3) {
+    if constexpr (CFG::PRIO == 1) {
       // issue priority falls as a workgroup advances, so the workgroups sharing a CU finish
       // together instead of oldest-first (the last one would otherwise run alone, latency-bound)
       const int left = nch - c;

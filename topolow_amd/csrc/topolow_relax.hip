@@ -205,27 +205,13 @@ struct ProfScope {
   }
 };
 
-// Stage-kernel geometry.  Production: the pipelined kernel (relax_kernels.h), 256 threads, 2 rows
-// per wave (8 rows per workgroup), register budget for 5 waves per SIMD -- the fastest of the
-// variants measured on MI355X.  A build with -DTOPOLOW_TUNING also
-// instantiates the barrier-staged kernel in several geometries and the ablation kernels,
-// selectable with TOPOLOW_SLAB_VARIANT=<n>.
-using CfgProd = StageCfg<256, 2, 0, 3, 0, 5>;   // CHUNK 0: PipeGeom picks it per dim; 3: falling priority
+// Stage-kernel geometry.  Production: 256 threads, 2 rows per wave (8 rows per workgroup), chunk
+// size picked per ndim (PipeGeom), falling issue priority, register budget for 5 waves per SIMD --
+// the fastest of the variants measured on MI355X.  A build with
+// -DTOPOLOW_TUNING also instantiates other chunk sizes / budgets (TOPOLOW_SLAB_VARIANT=<n>) and
+// the per-workgroup time stamps (TOPOLOW_WG_STAMPS=<file>).
+using CfgProd = StageCfg<256, 2, 0, 1, 5>;
 #ifdef TOPOLOW_TUNING
-using CfgOld = StageCfg<256, 2, 1024, 0, 0, 5>; // barrier-staged kernel, production until the pipelined one
-using CfgA = StageCfg<256, 4, 1024>;            // 16 rows / WG
-using CfgB = StageCfg<512, 2, 1024>;            // 16 rows / WG, twice the waves
-using CfgC = StageCfg<512, 2, 2560>;            // whole 10k/4 slab in one LDS image
-using CfgD = StageCfg<256, 2, 1024>;            // production geometry without the register budget
-using CfgE = StageCfg<512, 4, 1024>;            // 32 rows / WG
-using CfgF = StageCfg<256, 2, 1024, 1, 0, 4>;   // chunk loads up front, 4 waves/SIMD
-using CfgL = StageCfg<256, 2, 1024, 1, 0, 5>;   // chunk loads up front, 5 waves/SIMD
-using CfgM = StageCfg<256, 2, 512, 1, 0, 5>;    // 512-column chunks, loads up front
-using CfgG = StageCfg<256, 2, 1024, 0, 1>;      // memory only   (results wrong on purpose)
-using CfgH = StageCfg<256, 2, 1024, 0, 2>;      // arithmetic only (results wrong on purpose)
-using CfgI = StageCfg<256, 2, 1024, 0, 0, 8>;   // squeezed to 64 VGPRs
-using CfgJ = StageCfg<256, 2, 1024, 0, 0, 6>;   // squeezed to 80 VGPRs
-
 // TOPOLOW_WG_STAMPS=<file>: the stage kernel's workgroups stamp their start/end times; the last
 // launch's stamps are written to <file> as text when the session is destroyed.
 struct WgStamps {
@@ -264,24 +250,6 @@ int slab_variant() {
 #endif
 
 template <int DIM, typename real, typename CFG>
-void launch_stage_cfg(topolow_session* s, const void* pin, void* pout, RunState* st,
-                      SlabRanges rg, int iter1, double k) {
-  const int blocks = (s->rows() + CFG::ROWS - 1) / CFG::ROWS;
-  const size_t lds = sizeof(real) * DIM * CFG::CHUNK;
-  auto launch = [&](auto kern) {
-    if (lds > 64 * 1024) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), lds, s->stream, s->enc.p, s->ld,
-                       s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
-                       s->rowflags.p, st, rg, iter1, k, s->c_rep);
-  };
-  if (s->any_threshold) launch(&slab_stage_kernel<DIM, real, CFG, true>);
-  else launch(&slab_stage_kernel<DIM, real, CFG, false>);
-}
-
-template <int DIM, typename real, typename CFG>
 void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState* st,
                        SlabRanges rg, int iter1, double k) {
   const int blocks = (s->rows() + CFG::ROWS - 1) / CFG::ROWS;
@@ -303,30 +271,15 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
   if (s->rows() <= 0) return;
   ProfScope prof(s, &s->prof_stage);
   if (s->precision == TOPOLOW_PRECISION_F64) {
-    launch_stage_pipe<DIM, double, StageCfg<256, 2, 0>>(s, pin, pout, st, rg, iter1, k);
+    launch_stage_pipe<DIM, double, StageCfg<256, 2, 0, 1>>(s, pin, pout, st, rg, iter1, k);
   } else {
 #ifdef TOPOLOW_TUNING
     switch (slab_variant()) {
-      case 0: launch_stage_cfg<DIM, float, CfgA>(s, pin, pout, st, rg, iter1, k); break;
-      case 1: launch_stage_cfg<DIM, float, CfgB>(s, pin, pout, st, rg, iter1, k); break;
-      case 2: launch_stage_cfg<DIM, float, CfgC>(s, pin, pout, st, rg, iter1, k); break;
-      case 3: launch_stage_cfg<DIM, float, CfgD>(s, pin, pout, st, rg, iter1, k); break;
-      case 4: launch_stage_cfg<DIM, float, CfgE>(s, pin, pout, st, rg, iter1, k); break;
-      case 5: launch_stage_cfg<DIM, float, CfgF>(s, pin, pout, st, rg, iter1, k); break;
-      case 11: launch_stage_cfg<DIM, float, CfgL>(s, pin, pout, st, rg, iter1, k); break;
-      case 12: launch_stage_cfg<DIM, float, CfgM>(s, pin, pout, st, rg, iter1, k); break;
-      case 6: launch_stage_cfg<DIM, float, CfgG>(s, pin, pout, st, rg, iter1, k); break;
-      case 7: launch_stage_cfg<DIM, float, CfgH>(s, pin, pout, st, rg, iter1, k); break;
-      case 8: launch_stage_cfg<DIM, float, CfgI>(s, pin, pout, st, rg, iter1, k); break;
-      case 9: launch_stage_cfg<DIM, float, CfgJ>(s, pin, pout, st, rg, iter1, k); break;
-      case 10: launch_stage_cfg<DIM, float, CfgOld>(s, pin, pout, st, rg, iter1, k); break;
-      case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 25: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 26: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
-      case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 4>>(s, pin, pout, st, rg, iter1, k); break;
-      case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 0, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 0, 6>>(s, pin, pout, st, rg, iter1, k); break;
+      case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 1, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 4>>(s, pin, pout, st, rg, iter1, k); break;
+      case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 1, 5>>(s, pin, pout, st, rg, iter1, k); break;
+      case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 7>>(s, pin, pout, st, rg, iter1, k); break;
       default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k); break;
     }
 #else
