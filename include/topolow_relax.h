@@ -108,8 +108,8 @@ int topolow_optimize_layout_exact(
  * its own error_code / message-free status; the call itself still returns TOPOLOW_OK. */
 typedef struct topolow_problem {
   const double* initial_positions;     /* n x ndim, column-major */
-  const double* dissimilarity_matrix;  /* n x n, +Inf = unmeasured */
-  const int32_t* threshold_matrix;     /* n x n */
+  const double* dissimilarity_matrix;  /* n x n, +Inf = unmeasured; NULL together with           */
+  const int32_t* threshold_matrix;     /* n x n   threshold_matrix: the edge list IS the matrix   */
   const int32_t* degrees;              /* n */
   const int32_t* edge_i;
   const int32_t* edge_j;
@@ -119,6 +119,13 @@ typedef struct topolow_problem {
   int32_t n, ndim, n_iter, convergence_window, convergence_check_freq, reserved0;
   double k0, cooling_rate, c_repulsion, relative_epsilon;
   uint64_t seed;
+  /* Optional held-out pairs (0-based, any orientation) with their true dissimilarities: scored on
+   * the returned positions, sum |truth - distance| -- the OutSampleError of the reference's
+   * error_calculator_comparison (R/error_metrics.R:55-144) without materialising est_distances. */
+  const int32_t* holdout_i;
+  const int32_t* holdout_j;
+  const double* holdout_truth;
+  int64_t n_holdout;
 } topolow_problem;
 
 typedef struct topolow_result {
@@ -127,6 +134,8 @@ typedef struct topolow_result {
   int32_t converged, iterations, iterations_run, n_checks;
   int32_t error_code;                  /* TOPOLOW_OK or TOPOLOW_ERR_NONFINITE */
   int32_t error_iteration;             /* iteration reported by the non-finite guard */
+  double holdout_sum_abs;              /* sum |truth - distance| over the holdout pairs */
+  int64_t holdout_count;
 } topolow_result;
 
 int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow_result* results,

@@ -104,3 +104,63 @@ def test_fold_construction():
             mine.add((min(r, c), max(r, c)))
         assert not (mine & seen)
         seen |= mine
+
+
+def _coded_random(n, seed, named):
+    """Symmetric matrix with NA, ">"/"<" cells and a few cells whose mirror is NA."""
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(0.5, 6.0, (n, n)); d = np.triu(d, 1); d = d + d.T
+    codes = np.zeros((n, n), dtype=np.int32)
+    iu = np.triu_indices(n, 1)
+    for q in range(iu[0].size):
+        i, j = iu[0][q], iu[1][q]
+        u = rng.uniform()
+        if u < 0.35:
+            d[i, j] = d[j, i] = np.nan
+        elif u < 0.45:
+            codes[i, j] = codes[j, i] = 1 if rng.uniform() < 0.5 else -1
+        elif u < 0.48:
+            d[j, i] = np.nan                       # lower-triangle cell missing, upper present
+    names = [f"p{q}" for q in range(n)] if named else None
+    return core.CodedMatrix(d, codes, names, True)
+
+
+@pytest.mark.parametrize("source", ["hiv", "random_named", "random_unnamed"])
+def test_fold_builder_equals_the_dense_preparation(source):
+    """cv.FoldBuilder (cell list, no n x n work per fold) must hand the kernel exactly what
+    core.prepare_layout_call builds from the masked matrix, and its holdout list must be the
+    out-of-sample cells of error_calculator_comparison (R/adaptive_sampling.R:2600-2680)."""
+    if source == "hiv":
+        rows = list(csv.DictReader(open(os.path.join(GOLD, "hiv_distances.csv"))))
+        m = core.coded_matrix(antigenic.titers_list_to_matrix(rows, "Virus", "virusYear", "Antibody", None,
+                                                              "distance", sort=True))
+    else:
+        m = _coded_random(41, 5, source == "random_named")
+    n = m.values.shape[0]
+    fb = cv.FoldBuilder(m)
+    folds = cv.make_folds(m.values, 4, np.random.default_rng(3))
+    assert len(folds) == 4
+    for q, h in enumerate(folds):
+        r1, r2 = np.random.default_rng(100 + q), np.random.default_rng(100 + q)
+        masked = m.masked(h % n, h // n)
+        dense = core.prepare_layout_call(masked, 3, 50, 2.0, 0.02, 0.01, 1e-4, 5, None, False, 3, False, r1)
+        sparse, hold = fb.fold(h, 3, 50, 2.0, 0.02, 0.01, 1e-4, 5, 3, False, r2)
+        assert (dense.order is None) == (sparse.order is None)
+        if dense.order is not None:
+            assert np.array_equal(dense.order, sparse.order)
+        assert dense.names == sparse.names
+        for f in ("initial_positions", "degrees", "edge_i", "edge_j", "edge_dist", "edge_thresh"):
+            assert np.array_equal(getattr(dense, f), getattr(sparse, f)), f
+        assert r1.uniform() == r2.uniform()              # same draws taken from the stream
+        # holdout list == OutSampleError cells, for an arbitrary "prediction" in the returned numbering
+        est = np.random.default_rng(q).uniform(0, 5, (n, n)); est = (est + est.T) / 2
+        err = cv.error_calculator_comparison(est, m, masked, pred_names=dense.names, true_names=m.names)
+        oe = err["OutSampleError"]; oe = oe[~np.isnan(oe)]
+        mine = np.abs(hold[2] - est[hold[0], hold[1]])
+        assert mine.size == oe.size and mine.sum() == pytest.approx(np.abs(oe).sum(), rel=1e-13)
+    # preserve_order = TRUE: no reordering in either
+    d2 = core.prepare_layout_call(m.masked(folds[0] % n, folds[0] // n), 2, 50, 2.0, 0.02, 0.01, 1e-4, 5, None,
+                                  False, 3, True, np.random.default_rng(1))
+    s2, _ = fb.fold(folds[0], 2, 50, 2.0, 0.02, 0.01, 1e-4, 5, 3, True, np.random.default_rng(1))
+    assert s2.order is None and np.array_equal(d2.edge_i, s2.edge_i) and np.array_equal(d2.degrees, s2.degrees)
+    assert np.array_equal(d2.initial_positions, s2.initial_positions)

@@ -104,3 +104,40 @@ def test_config5_sweep_many_parameter_sets_in_one_launch():
     batch, _ = _native.optimize_layout_exact_batch([call, call], seeds=[99, 100])
     assert np.array_equal(batch[0].positions, alone.positions) and batch[0].iterations == alone.iterations
     assert not np.array_equal(batch[1].positions, alone.positions)
+
+
+def test_sparse_cv_path_equals_the_dense_sequence(monkeypatch):
+    """The sweep that never builds an n x n array (cell-list folds, edge-list-defined problems,
+    holdout scored on the device) must give what the reference's own sequence gives on the same
+    folds: masked matrix -> prepare_layout_call -> est_distances -> error_calculator_comparison."""
+    import dataclasses
+    hv = hiv_matrix()
+    sets = [HIV, dict(N=3, k0=5.0, cooling_rate=0.02, c_repulsion=0.005),
+            dict(N=2, k0=-1.0, cooling_rate=0.02, c_repulsion=0.005)]       # invalid k0 -> NA row
+    a, _, na = cv.likelihood_sweep(hv, sets, 300, 1e-4, folds=5, rng=np.random.default_rng(9), path="dense")
+    b, _, nb = cv.likelihood_sweep(hv, sets, 300, 1e-4, folds=5, rng=np.random.default_rng(9), path="sparse")
+    assert na == nb == 10
+    for x, y in zip(a[:2], b[:2]):
+        assert y["Holdout_MAE"] == pytest.approx(x["Holdout_MAE"], rel=1e-12)
+        assert y["NLL"] == pytest.approx(x["NLL"], rel=1e-12)
+        assert y["mean_iter"] == x["mean_iter"] and y["pct_converged"] == x["pct_converged"]
+    assert np.isnan(a[2]["Holdout_MAE"]) and np.isnan(b[2]["Holdout_MAE"])
+    # the edge list standing for the matrix, on the dense-matrix kernel too (matrix rebuilt from it)
+    call = core.prepare_layout_call(hv, 3, 120, 4.0, 0.03, 0.001, 1e-4, 5, None, False, 3, False,
+                                    np.random.default_rng(5))
+    bare = dataclasses.replace(call, dissimilarity_matrix=None, threshold_matrix=None)
+    hold = (np.array([0, 5, 7], dtype=np.int32), np.array([3, 1, 7], dtype=np.int32), np.array([1.0, 2.5, 0.0]))
+    for dense_kernel in ("", "1"):
+        if dense_kernel:
+            monkeypatch.setenv("TOPOLOW_GS_DENSE", "1")
+        full, _ = _native.optimize_layout_exact_batch([call], seeds=[3])
+        lean, _ = _native.optimize_layout_exact_batch([bare], seeds=[3], holdouts=[hold])
+        assert np.array_equal(full[0].positions, lean[0].positions) and full[0].final_mae == lean[0].final_mae
+        p = lean[0].positions
+        want = sum(abs(t - np.linalg.norm(p[i] - p[j])) for i, j, t in zip(*hold))
+        assert lean[0].info["holdout_count"] == 3
+        assert lean[0].info["holdout_sum_abs"] == pytest.approx(want, rel=1e-12)
+    # a malformed stand-in list is refused
+    bad = dataclasses.replace(bare, edge_i=bare.edge_j, edge_j=bare.edge_i)
+    with pytest.raises(_native.NativeError):
+        _native.optimize_layout_exact_batch([bad], seeds=[3])

@@ -58,14 +58,17 @@ class TopolowProblem(C.Structure):
                 ("n_edges", C.c_int64), ("n", C.c_int32), ("ndim", C.c_int32), ("n_iter", C.c_int32),
                 ("convergence_window", C.c_int32), ("convergence_check_freq", C.c_int32),
                 ("reserved0", C.c_int32), ("k0", C.c_double), ("cooling_rate", C.c_double),
-                ("c_repulsion", C.c_double), ("relative_epsilon", C.c_double), ("seed", C.c_uint64)]
+                ("c_repulsion", C.c_double), ("relative_epsilon", C.c_double), ("seed", C.c_uint64),
+                ("holdout_i", C.POINTER(C.c_int32)), ("holdout_j", C.POINTER(C.c_int32)),
+                ("holdout_truth", C.POINTER(C.c_double)), ("n_holdout", C.c_int64)]
 
 
 class TopolowResult(C.Structure):
     _fields_ = [("positions_out", C.POINTER(C.c_double)), ("final_mae", C.c_double),
                 ("final_k", C.c_double), ("converged", C.c_int32), ("iterations", C.c_int32),
                 ("iterations_run", C.c_int32), ("n_checks", C.c_int32), ("error_code", C.c_int32),
-                ("error_iteration", C.c_int32)]
+                ("error_iteration", C.c_int32), ("holdout_sum_abs", C.c_double),
+                ("holdout_count", C.c_int64)]
 
 
 # Additive backend options (the reference's function signatures stay untouched; this mirrors
@@ -304,9 +307,13 @@ def optimize_layout_exact(call) -> NativeResult:
         call.convergence_check_freq, call.verbose)
 
 
-def optimize_layout_exact_batch(calls, seeds=None, precision="f64", device=-1):
-    """Relaxes a list of core.LayoutCall objects as ONE grid of the exact-GS kernel (one workgroup
-    per embedding).  Returns (list of NativeResult-or-NativeError, device_seconds)."""
+def optimize_layout_exact_batch(calls, seeds=None, precision="f64", device=-1, holdouts=None):
+    """Relaxes a list of calls as ONE grid of the exact-GS kernel (one workgroup per embedding).
+    A call is a core.LayoutCall, or any object with the same fields whose `dissimilarity_matrix` is
+    None: its edge list then IS the matrix (every unlisted pair unmeasured) and no n x n array is
+    built or uploaded.  `holdouts[b]` = (i, j, truth) arrays of held-out pairs to score on the
+    returned positions (info["holdout_sum_abs"], info["holdout_count"]).
+    Returns (list of NativeResult-or-NativeError, device_seconds)."""
     lib = load()
     count = len(calls)
     probs = (TopolowProblem * count)()
@@ -316,23 +323,32 @@ def optimize_layout_exact_batch(calls, seeds=None, precision="f64", device=-1):
     for b, c in enumerate(calls):
         pos0 = _f64F(c.initial_positions)
         n, dim = pos0.shape
-        D, T = _f64F(c.dissimilarity_matrix), _i32F(c.threshold_matrix)
         deg = np.ascontiguousarray(c.degrees, dtype=np.int32)
         ei = np.ascontiguousarray(c.edge_i, dtype=np.int32)
         ej = np.ascontiguousarray(c.edge_j, dtype=np.int32)
         ed = np.ascontiguousarray(c.edge_dist, dtype=np.float64)
         et = np.ascontiguousarray(c.edge_thresh, dtype=np.int32)
         out = np.zeros((n, dim), dtype=np.float64, order="F")
-        keep.append((pos0, D, T, deg, ei, ej, ed, et))
-        outs.append(out)
         p = probs[b]
-        p.initial_positions, p.dissimilarity_matrix, p.threshold_matrix = _dp(pos0), _dp(D), _ip(T)
+        if c.dissimilarity_matrix is not None:
+            D, T = _f64F(c.dissimilarity_matrix), _i32F(c.threshold_matrix)
+            p.dissimilarity_matrix, p.threshold_matrix = _dp(D), _ip(T)
+            keep.append((D, T))
+        keep.append((pos0, deg, ei, ej, ed, et))
+        outs.append(out)
+        p.initial_positions = _dp(pos0)
         p.degrees, p.edge_i, p.edge_j, p.edge_dist, p.edge_thresh = _ip(deg), _ip(ei), _ip(ej), _dp(ed), _ip(et)
         p.n_edges, p.n, p.ndim, p.n_iter = int(ei.shape[0]), n, dim, int(c.n_iter)
         p.convergence_window, p.convergence_check_freq = int(c.convergence_window), int(c.convergence_check_freq)
         p.k0, p.cooling_rate, p.c_repulsion = float(c.k0), float(c.cooling_rate), float(c.c_repulsion)
         p.relative_epsilon = float(c.relative_epsilon)
         p.seed = int(seeds[b] if seeds is not None else _host_rng.integers(0, 2 ** 63 - 1)) & 0xFFFFFFFFFFFFFFFF
+        if holdouts is not None and holdouts[b] is not None and len(holdouts[b][0]) > 0:
+            hi = np.ascontiguousarray(holdouts[b][0], dtype=np.int32)
+            hj = np.ascontiguousarray(holdouts[b][1], dtype=np.int32)
+            ht = np.ascontiguousarray(holdouts[b][2], dtype=np.float64)
+            keep.append((hi, hj, ht))
+            p.holdout_i, p.holdout_j, p.holdout_truth, p.n_holdout = _ip(hi), _ip(hj), _dp(ht), int(hi.shape[0])
         ress[b].positions_out = _dp(out)
     secs = C.c_double(0.0)
     err = C.create_string_buffer(512)
@@ -349,7 +365,9 @@ def optimize_layout_exact_batch(calls, seeds=None, precision="f64", device=-1):
             results.append(NativeResult(np.ascontiguousarray(outs[b]), bool(r.converged), int(r.iterations),
                                         float(r.final_mae), float(r.final_k),
                                         dict(schedule="gs", precision=precision, iterations_run=r.iterations_run,
-                                             n_checks=r.n_checks, seed=int(probs[b].seed))))
+                                             n_checks=r.n_checks, seed=int(probs[b].seed),
+                                             holdout_sum_abs=float(r.holdout_sum_abs),
+                                             holdout_count=int(r.holdout_count))))
     return results, float(secs.value)
 
 

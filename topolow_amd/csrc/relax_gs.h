@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -83,6 +84,8 @@ struct GsOut {
   int n_checks;
   int nonfinite_iter;  // != 0: "Numerical instability at iteration %d"
   int pad;
+  double hold_sum;               // sum |truth - distance| over the holdout pairs, final positions
+  unsigned long long hold_cnt;
 };
 
 template <typename real>
@@ -98,6 +101,9 @@ struct GsDev {
   const unsigned short* erow;    // n_edges
   const real* etgt;              // n_edges (targets in the kernel's precision)
   const int8_t* ecode;           // n_edges
+  // held-out pairs scored on the final positions (cross-validation; may be empty)
+  const int* hi; const int* hj; const double* ht;
+  long long n_hold;
   real* pos;             // n x dim row-major: in = initial positions, out = best positions
   real* best;            // n x dim scratch
   GsOut* out;
@@ -467,8 +473,27 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
   __syncthreads();
   // restore the best snapshot (reference :324-327, :368-374)
   for (int q = tid; q < n * DIM; q += nthr) P.pos[q] = P.best[q];
+  // Out-of-sample error of the returned map (what the reference gets from as.matrix(dist()) +
+  // error_calculator_comparison, R/core.R:474, R/error_metrics.R:55-144): f64 distances of the
+  // held-out pairs against their true values.
+  double hs = 0.0;
+  unsigned long long hc = 0;
+  for (long long e = tid; e < P.n_hold; e += nthr) {
+    const int a = P.hi[e], b = P.hj[e];
+    double q = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const double diff = (double)P.best[(size_t)a * DIM + d] - (double)P.best[(size_t)b * DIM + d];
+      q += diff * diff;
+    }
+    hs += fabs(P.ht[e] - sqrt(q));
+    ++hc;
+  }
+  if (P.n_hold > 0) gs_block_sum(hs, hc, sh_s, sh_c);   // block-uniform condition
   if (tid == 0) {
     GsOut o;
+    o.hold_sum = hs;
+    o.hold_cnt = hc;
     o.final_mae = ctl.best_mae;
     o.final_k = ctl.best_k;
     o.converged = converged;
@@ -494,6 +519,9 @@ struct GsProblem {
   int n, dim, n_iter, window, check_freq;
   double k0, cooling, c_rep, eps;
   uint64_t seed;
+  // D == T == nullptr: the edge list DEFINES the matrix (every unlisted pair is unmeasured)
+  const int32_t* hold_i = nullptr; const int32_t* hold_j = nullptr; const double* hold_truth = nullptr;
+  int64_t n_hold = 0;
 };
 
 struct GsResult {
@@ -501,6 +529,8 @@ struct GsResult {
   int converged, iterations, iters_run, n_checks;
   int nonfinite_iter = 0;  // != 0: the non-finite guard fired at this iteration
   double final_mae, final_k;
+  double hold_sum = 0.0;
+  long long hold_count = 0;
 };
 
 inline size_t gs_lds_bytes(int n, int dim, size_t real_size, long long csr_edges = 0) {
@@ -530,21 +560,6 @@ struct GsHipError { int code; std::string msg; };
     if (e_ != hipSuccess) throw GsHipError{TOPOLOW_ERR_HIP, std::string(#expr) + ": " +   \
                                                                 hipGetErrorString(e_)};   \
   } while (0)
-
-template <typename real>
-struct GsDeviceProblem {
-  real* tm = nullptr; int8_t* cm = nullptr; double* gplus = nullptr;
-  int* ei = nullptr; int* ej = nullptr; double* et = nullptr; int8_t* ec = nullptr;
-  int* row_off = nullptr; unsigned short* ecol = nullptr; unsigned short* erow = nullptr;
-  real* etgt = nullptr;
-  real* pos = nullptr; real* best = nullptr;
-  void release() {
-    (void)hipFree(tm); (void)hipFree(cm); (void)hipFree(gplus); (void)hipFree(ei); (void)hipFree(ej);
-    (void)hipFree(et); (void)hipFree(ec); (void)hipFree(row_off); (void)hipFree(ecol); (void)hipFree(erow);
-    (void)hipFree(etgt);
-    (void)hipFree(pos); (void)hipFree(best);
-  }
-};
 
 template <int DIM, typename real>
 void gs_launch(const GsDev<real>* d_problems, int count, int threads, size_t lds, bool sparse,
@@ -583,80 +598,136 @@ inline bool gs_edges_match_matrix(const GsProblem& p) {
   return true;
 }
 
+// An edge list that may stand for the matrix: 0 <= i < j < n, finite targets, no pair twice.
+inline bool gs_edges_well_formed(const GsProblem& p) {
+  const int n = p.n;
+  std::vector<long long> key((size_t)p.n_edges);
+  for (long long e = 0; e < p.n_edges; ++e) {
+    const int a = p.edge_i[e], b = p.edge_j[e];
+    if (a < 0 || b <= a || b >= n || !std::isfinite(p.edge_dist[e])) return false;
+    key[(size_t)e] = (long long)a * n + b;
+  }
+  std::sort(key.begin(), key.end());
+  return std::adjacent_find(key.begin(), key.end()) == key.end();
+}
+
+// Host/device staging of a whole batch: every array of every problem lives in ONE host buffer that
+// goes to the device with one copy (thousands of small embeddings per launch otherwise spend their
+// time in hipMalloc / hipMemcpy calls); positions sit together at the front so they come back with
+// one copy as well.
+class GsArena {
+ public:
+  size_t reserve(size_t bytes) {
+    const size_t at = size_;
+    size_ += (bytes + 255) & ~(size_t)255;
+    return at;
+  }
+  void commit() { host_.assign(size_, 0); }
+  template <typename T> T* host(size_t off) { return reinterpret_cast<T*>(host_.data() + off); }
+  template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(dev_ + off); }
+  void upload() {
+    GS_TRY(hipMalloc((void**)&dev_, size_ ? size_ : 256));
+    GS_TRY(hipMemcpy(dev_, host_.data(), size_, hipMemcpyHostToDevice));
+  }
+  void download_front(size_t bytes) { GS_TRY(hipMemcpy(host_.data(), dev_, bytes, hipMemcpyDeviceToHost)); }
+  ~GsArena() { (void)hipFree(dev_); }
+ private:
+  size_t size_ = 0;
+  std::vector<unsigned char> host_;
+  unsigned char* dev_ = nullptr;
+};
+
 template <typename real>
 int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* device_seconds,
                    char* errbuf, size_t errlen) {
-  std::vector<GsDeviceProblem<real>> dev(count);
-  std::vector<GsDev<real>> h(count);
-  GsOut* d_out = nullptr;
-  GsDev<real>* d_problems = nullptr;
   int rc = TOPOLOW_OK;
-  auto cleanup = [&] {
-    for (auto& d : dev) d.release();
-    (void)hipFree(d_out);
-    (void)hipFree(d_problems);
-  };
+  unsigned char* d_scratch = nullptr;   // best snapshots: device only
   try {
     const int dim = pbs[0].dim;
     size_t lds_max = 0;
     int n_max = 0;
     // one kernel instance per launch: the LDS-resident table is used when EVERY problem of the
-    // batch qualifies (edge list == matrix, n < 65536, table within the LDS budget)
+    // batch qualifies (edge list == matrix, or edge list given as the matrix; n <= 2048; table
+    // within the LDS budget)
     bool sparse = getenv("TOPOLOW_GS_DENSE") == nullptr;
-    for (int b = 0; b < count && sparse; ++b) {
-      const GsProblem& p = pbs[b];
-      sparse = p.n <= 2048 && p.n_edges > 0 && p.n_edges < 65535 &&
-               gs_lds_bytes(p.n, dim, sizeof(real), p.n_edges) <= kGsSparseLdsBudget &&
-               gs_edges_match_matrix(p);
-    }
-    GS_TRY(hipMalloc((void**)&d_out, sizeof(GsOut) * count));
     for (int b = 0; b < count; ++b) {
       const GsProblem& p = pbs[b];
       if (p.dim != dim) throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "batch must share ndim"};
       if (p.n < 2) throw GsHipError{TOPOLOW_ERR_TOO_FEW_POINTS, "Need at least 2 points for embedding"};
+      if ((p.D == nullptr) != (p.T == nullptr))
+        throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "dissimilarity and threshold matrices come together"};
+      if (p.D == nullptr && !gs_edges_well_formed(p))
+        throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT,
+                         "edge list that stands for the matrix needs 0 <= i < j < n, finite targets, no pair twice"};
+      for (long long e = 0; e < p.n_hold; ++e)
+        if (p.hold_i[e] < 0 || p.hold_i[e] >= p.n || p.hold_j[e] < 0 || p.hold_j[e] >= p.n)
+          throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "holdout pair out of range"};
+      if (sparse)
+        sparse = p.n <= 2048 && p.n_edges > 0 && p.n_edges < 65535 &&
+                 gs_lds_bytes(p.n, dim, sizeof(real), p.n_edges) <= kGsSparseLdsBudget &&
+                 (p.D == nullptr || gs_edges_match_matrix(p));
+    }
+    // ---- layout ----
+    struct Off {
+      size_t pos, gplus, tm = 0, cm = 0, ei = 0, ej = 0, et = 0, ec, roff = 0, ecol = 0, erow = 0, etgt = 0,
+             hi = 0, hj = 0, ht = 0, best;
+    };
+    std::vector<Off> off(count);
+    GsArena A;
+    size_t best_total = 0;
+    for (int b = 0; b < count; ++b) off[b].pos = A.reserve((size_t)pbs[b].n * dim * sizeof(real));
+    const size_t pos_region = A.reserve(0);
+    const size_t o_out = A.reserve(sizeof(GsOut) * count);
+    const size_t o_prob = A.reserve(sizeof(GsDev<real>) * count);
+    for (int b = 0; b < count; ++b) {
+      const GsProblem& p = pbs[b];
       const size_t lds = gs_lds_bytes(p.n, dim, sizeof(real), sparse ? p.n_edges : 0);
       if (lds > 160 * 1024)
         throw GsHipError{TOPOLOW_ERR_UNSUPPORTED,
                          "problem too large for the single-workgroup GS kernel (LDS); use the slab schedule"};
       lds_max = std::max(lds_max, lds);
       n_max = std::max(n_max, p.n);
-      const size_t nn = (size_t)p.n * p.n, nd = (size_t)p.n * dim, ne = (size_t)p.n_edges;
-      std::vector<real> tm(nn), pos(nd);
-      std::vector<int8_t> cm(nn), ec(ne ? ne : 1);
-      std::vector<double> g(p.n);
-      for (size_t q = 0; q < nn; ++q) {
-        tm[q] = (real)p.D[q];
-        const int c = p.T[q];
-        cm[q] = (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : -1));  // reference else-branch = "<"
+      const size_t nn = (size_t)p.n * p.n, ne = (size_t)p.n_edges, ne1 = ne ? ne : 1;
+      Off& o = off[b];
+      o.gplus = A.reserve(p.n * 8);
+      o.ec = A.reserve(ne1);
+      if (sparse) {
+        o.roff = A.reserve((p.n + 1) * 4);
+        o.ecol = A.reserve(ne1 * 2);
+        o.erow = A.reserve(ne1 * 2);
+        o.etgt = A.reserve(ne1 * sizeof(real));
+      } else {
+        o.tm = A.reserve(nn * sizeof(real));
+        o.cm = A.reserve(nn);
+        o.ei = A.reserve(ne1 * 4);
+        o.ej = A.reserve(ne1 * 4);
+        o.et = A.reserve(ne1 * 8);
       }
+      if (p.n_hold > 0) {
+        o.hi = A.reserve(p.n_hold * 4);
+        o.hj = A.reserve(p.n_hold * 4);
+        o.ht = A.reserve(p.n_hold * 8);
+      }
+      o.best = best_total;
+      best_total += ((size_t)p.n * dim * sizeof(real) + 255) & ~(size_t)255;
+    }
+    A.commit();
+    // ---- fill ----
+    for (int b = 0; b < count; ++b) {
+      const GsProblem& p = pbs[b];
+      const Off& o = off[b];
+      const size_t nn = (size_t)p.n * p.n, ne = (size_t)p.n_edges;
+      real* pos = A.host<real>(o.pos);
+      double* g = A.host<double>(o.gplus);
       for (int i = 0; i < p.n; ++i) {
-        g[i] = (double)p.degrees[i] + 1.0;
+        g[i] = (double)p.degrees[i] + 1.0;   // reference :137-140
         for (int d = 0; d < dim; ++d) pos[(size_t)i * dim + d] = (real)p.initial_positions[i + (size_t)d * p.n];
       }
-      for (size_t e = 0; e < ne; ++e) {
-        const int c = p.edge_thresh[e];
-        ec[e] = (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : (c == -1 ? -1 : 2)));
-      }
-      GsDeviceProblem<real>& d = dev[b];
-      GS_TRY(hipMalloc((void**)&d.tm, nn * sizeof(real)));
-      GS_TRY(hipMalloc((void**)&d.cm, nn));
-      GS_TRY(hipMalloc((void**)&d.gplus, p.n * 8));
-      GS_TRY(hipMalloc((void**)&d.ei, (ne ? ne : 1) * 4));
-      GS_TRY(hipMalloc((void**)&d.ej, (ne ? ne : 1) * 4));
-      GS_TRY(hipMalloc((void**)&d.et, (ne ? ne : 1) * 8));
-      GS_TRY(hipMalloc((void**)&d.ec, (ne ? ne : 1)));
-      GS_TRY(hipMalloc((void**)&d.pos, nd * sizeof(real)));
-      GS_TRY(hipMalloc((void**)&d.best, nd * sizeof(real)));
-      GS_TRY(hipMemcpy(d.tm, tm.data(), nn * sizeof(real), hipMemcpyHostToDevice));
-      GS_TRY(hipMemcpy(d.cm, cm.data(), nn, hipMemcpyHostToDevice));
-      GS_TRY(hipMemcpy(d.gplus, g.data(), p.n * 8, hipMemcpyHostToDevice));
-      if (ne) {
-        GS_TRY(hipMemcpy(d.ei, p.edge_i, ne * 4, hipMemcpyHostToDevice));
-        GS_TRY(hipMemcpy(d.ej, p.edge_j, ne * 4, hipMemcpyHostToDevice));
-        GS_TRY(hipMemcpy(d.et, p.edge_dist, ne * 8, hipMemcpyHostToDevice));
-        GS_TRY(hipMemcpy(d.ec, ec.data(), ne, hipMemcpyHostToDevice));
-      }
-      GS_TRY(hipMemcpy(d.pos, pos.data(), nd * sizeof(real), hipMemcpyHostToDevice));
+      auto code_of = [](int c) { return (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : -1)); };  // else-branch = "<"
+      // edge codes keep "neither 0, 1 nor -1" apart: such a pair moves like "<" (:236-242) but never
+      // counts in the error (:68-76 compares with -1 exactly)
+      auto edge_code = [](int c) { return (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : (c == -1 ? -1 : 2))); };
+      int8_t* ec = A.host<int8_t>(o.ec);
       if (sparse) {
         // CSR over rows (entries sorted by row, then column); the caller's list is column-major
         std::vector<long long> order(ne);
@@ -664,36 +735,75 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
         std::sort(order.begin(), order.end(), [&](long long x, long long y) {
           return p.edge_i[x] != p.edge_i[y] ? p.edge_i[x] < p.edge_i[y] : p.edge_j[x] < p.edge_j[y];
         });
-        std::vector<int> roff(p.n + 1, 0);
-        std::vector<unsigned short> col(ne), row(ne);
-        std::vector<real> tgt(ne);
-        std::vector<int8_t> code(ne);
+        int* roff = A.host<int>(o.roff);
+        unsigned short* col = A.host<unsigned short>(o.ecol);
+        unsigned short* row = A.host<unsigned short>(o.erow);
+        real* tgt = A.host<real>(o.etgt);
         for (size_t q = 0; q < ne; ++q) {
           const long long e = order[q];
-          row[q] = (unsigned short)p.edge_i[e]; col[q] = (unsigned short)p.edge_j[e];
-          tgt[q] = (real)p.edge_dist[e]; code[q] = ec[e];
+          row[q] = (unsigned short)p.edge_i[e];
+          col[q] = (unsigned short)p.edge_j[e];
+          tgt[q] = (real)p.edge_dist[e];
+          ec[q] = edge_code(p.edge_thresh[e]);
           roff[p.edge_i[e] + 1] += 1;
         }
         for (int i = 0; i < p.n; ++i) roff[i + 1] += roff[i];
-        GS_TRY(hipMalloc((void**)&d.row_off, (p.n + 1) * 4));
-        GS_TRY(hipMalloc((void**)&d.ecol, ne * 2));
-        GS_TRY(hipMalloc((void**)&d.erow, ne * 2));
-        GS_TRY(hipMemcpy(d.row_off, roff.data(), (p.n + 1) * 4, hipMemcpyHostToDevice));
-        GS_TRY(hipMemcpy(d.ecol, col.data(), ne * 2, hipMemcpyHostToDevice));
-        GS_TRY(hipMemcpy(d.erow, row.data(), ne * 2, hipMemcpyHostToDevice));
-        GS_TRY(hipMalloc((void**)&d.etgt, ne * sizeof(real)));
-        GS_TRY(hipMemcpy(d.etgt, tgt.data(), ne * sizeof(real), hipMemcpyHostToDevice));
-        GS_TRY(hipMemcpy(d.ec, code.data(), ne, hipMemcpyHostToDevice));       // reuse: sorted codes
+      } else {
+        real* tm = A.host<real>(o.tm);
+        int8_t* cm = A.host<int8_t>(o.cm);
+        if (p.D != nullptr) {
+          for (size_t q = 0; q < nn; ++q) { tm[q] = (real)p.D[q]; cm[q] = code_of(p.T[q]); }
+        } else {   // the edge list is the matrix: unlisted pairs are unmeasured, the diagonal is 0
+          for (size_t q = 0; q < nn; ++q) tm[q] = (real)INFINITY;
+          for (int i = 0; i < p.n; ++i) tm[(size_t)i * p.n + i] = 0;
+          for (size_t e = 0; e < ne; ++e) {
+            const size_t up = (size_t)p.edge_i[e] + (size_t)p.edge_j[e] * p.n;
+            const size_t lo = (size_t)p.edge_j[e] + (size_t)p.edge_i[e] * p.n;
+            tm[up] = tm[lo] = (real)p.edge_dist[e];
+            cm[up] = cm[lo] = code_of(p.edge_thresh[e]);
+          }
+        }
+        std::memcpy(A.host<int>(o.ei), p.edge_i, ne * 4);
+        std::memcpy(A.host<int>(o.ej), p.edge_j, ne * 4);
+        std::memcpy(A.host<double>(o.et), p.edge_dist, ne * 8);
+        for (size_t e = 0; e < ne; ++e) ec[e] = edge_code(p.edge_thresh[e]);
       }
-      GsDev<real>& k = h[b];
-      k.tm = d.tm; k.cm = d.cm; k.gplus = d.gplus; k.ei = d.ei; k.ej = d.ej; k.et = d.et; k.ec = d.ec;
-      k.row_off = d.row_off; k.ecol = d.ecol; k.erow = d.erow; k.etgt = d.etgt; k.ecode = d.ec;
-      k.pos = d.pos; k.best = d.best; k.out = d_out + b; k.n_edges = p.n_edges;
-      k.k0 = p.k0; k.cooling = p.cooling; k.c_rep = p.c_rep; k.eps = p.eps; k.seed = p.seed;
-      k.n = p.n; k.n_iter = p.n_iter; k.check_freq = p.check_freq; k.window = p.window;
+      if (p.n_hold > 0) {
+        std::memcpy(A.host<int>(o.hi), p.hold_i, (size_t)p.n_hold * 4);
+        std::memcpy(A.host<int>(o.hj), p.hold_j, (size_t)p.n_hold * 4);
+        std::memcpy(A.host<double>(o.ht), p.hold_truth, (size_t)p.n_hold * 8);
+      }
     }
-    GS_TRY(hipMalloc((void**)&d_problems, sizeof(GsDev<real>) * count));
-    GS_TRY(hipMemcpy(d_problems, h.data(), sizeof(GsDev<real>) * count, hipMemcpyHostToDevice));
+    GS_TRY(hipMalloc((void**)&d_scratch, best_total ? best_total : 256));
+    A.upload();   // device addresses exist from here on; the problem table follows with its own copy
+    {
+      std::vector<GsDev<real>> h(count);
+      for (int b = 0; b < count; ++b) {
+        const GsProblem& p = pbs[b];
+        const Off& o = off[b];
+        GsDev<real>& k = h[b];
+        std::memset(&k, 0, sizeof k);
+        k.gplus = A.dev<double>(o.gplus);
+        k.ec = k.ecode = A.dev<int8_t>(o.ec);
+        if (sparse) {
+          k.row_off = A.dev<int>(o.roff); k.ecol = A.dev<unsigned short>(o.ecol);
+          k.erow = A.dev<unsigned short>(o.erow); k.etgt = A.dev<real>(o.etgt);
+        } else {
+          k.tm = A.dev<real>(o.tm); k.cm = A.dev<int8_t>(o.cm);
+          k.ei = A.dev<int>(o.ei); k.ej = A.dev<int>(o.ej); k.et = A.dev<double>(o.et);
+        }
+        if (p.n_hold > 0) { k.hi = A.dev<int>(o.hi); k.hj = A.dev<int>(o.hj); k.ht = A.dev<double>(o.ht); }
+        k.n_hold = p.n_hold;
+        k.pos = A.dev<real>(o.pos);
+        k.best = reinterpret_cast<real*>(d_scratch + o.best);
+        k.out = A.dev<GsOut>(o_out) + b;
+        k.n_edges = p.n_edges;
+        k.k0 = p.k0; k.cooling = p.cooling; k.c_rep = p.c_rep; k.eps = p.eps; k.seed = p.seed;
+        k.n = p.n; k.n_iter = p.n_iter; k.check_freq = p.check_freq; k.window = p.window;
+      }
+      GS_TRY(hipMemcpy(A.dev<GsDev<real>>(o_prob), h.data(), sizeof(GsDev<real>) * count, hipMemcpyHostToDevice));
+    }
+    const GsDev<real>* d_problems = A.dev<GsDev<real>>(o_prob);
     int threads = (((n_max + 1) / 2) + 63) & ~63;
     threads = std::max(128, std::min(1024, threads));
     hipEvent_t e0, e1;
@@ -714,8 +824,9 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (device_seconds) *device_seconds = ms * 1e-3;
-    std::vector<GsOut> outs(count);
-    GS_TRY(hipMemcpy(outs.data(), d_out, sizeof(GsOut) * count, hipMemcpyDeviceToHost));
+    A.download_front(o_out + sizeof(GsOut) * count);   // positions and results
+    (void)pos_region;
+    const GsOut* outs = A.host<GsOut>(o_out);
     for (int b = 0; b < count; ++b) {
       const GsProblem& p = pbs[b];
       const GsOut& o = outs[b];
@@ -725,20 +836,19 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
                    o.nonfinite_iter);
         rc = TOPOLOW_ERR_NONFINITE;
       }
-      const size_t nd = (size_t)p.n * dim;
-      std::vector<real> pos(nd);
-      GS_TRY(hipMemcpy(pos.data(), dev[b].pos, nd * sizeof(real), hipMemcpyDeviceToHost));
+      const real* pos = A.host<real>(off[b].pos);
       for (int i = 0; i < p.n; ++i)
         for (int d = 0; d < dim; ++d) res[b].positions[i + (size_t)d * p.n] = (double)pos[(size_t)i * dim + d];
       res[b].converged = o.converged; res[b].iterations = o.iterations; res[b].iters_run = o.iters_run;
       res[b].n_checks = o.n_checks; res[b].final_mae = o.final_mae; res[b].final_k = o.final_k;
       res[b].nonfinite_iter = o.nonfinite_iter;
+      res[b].hold_sum = o.hold_sum; res[b].hold_count = (long long)o.hold_cnt;
     }
   } catch (const GsHipError& e) {
     if (errbuf && errlen) snprintf(errbuf, errlen, "%s", e.msg.c_str());
     rc = e.code;
   }
-  cleanup();
+  (void)hipFree(d_scratch);
   return rc;
 }
 

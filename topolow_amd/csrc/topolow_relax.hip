@@ -1085,6 +1085,8 @@ int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow
         g.n_iter = p.n_iter; g.window = p.convergence_window; g.check_freq = p.convergence_check_freq;
         g.k0 = p.k0; g.cooling = p.cooling_rate; g.c_rep = p.c_repulsion; g.eps = p.relative_epsilon;
         g.seed = p.seed;
+        g.hold_i = p.holdout_i; g.hold_j = p.holdout_j; g.hold_truth = p.holdout_truth;
+        g.n_hold = (p.holdout_i && p.holdout_j && p.holdout_truth) ? p.n_holdout : 0;
         GsResult r;
         r.positions = results[b].positions_out;
         pbs.push_back(g); res.push_back(r); idx.push_back(b);
@@ -1102,6 +1104,8 @@ int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow
         o.iterations = res[q].iterations; o.iterations_run = res[q].iters_run; o.n_checks = res[q].n_checks;
         o.error_code = res[q].nonfinite_iter ? TOPOLOW_ERR_NONFINITE : TOPOLOW_OK;
         o.error_iteration = res[q].nonfinite_iter;
+        o.holdout_sum_abs = res[q].hold_sum;
+        o.holdout_count = res[q].hold_count;
       }
     }
   });

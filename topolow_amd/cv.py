@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import math
 import warnings
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -78,11 +79,130 @@ def make_folds(values: np.ndarray, folds: int, rng: np.random.Generator):
     return out
 
 
+@dataclass
+class SparseCall:
+    """A `core.LayoutCall` without the two n x n arrays: the edge list IS the matrix (the batch
+    entry of the library accepts that form, include/topolow_relax.h)."""
+    initial_positions: np.ndarray
+    degrees: np.ndarray
+    edge_i: np.ndarray
+    edge_j: np.ndarray
+    edge_dist: np.ndarray
+    edge_thresh: np.ndarray
+    n_iter: int
+    k0: float
+    cooling_rate: float
+    c_repulsion: float
+    relative_epsilon: float
+    convergence_window: int
+    convergence_check_freq: int
+    names: Optional[List[str]] = None
+    order: Optional[np.ndarray] = None
+    dissimilarity_matrix: None = None
+    threshold_matrix: None = None
+
+
+class FoldBuilder:
+    """`prepare_layout_call(masked matrix)` + the fold's out-of-sample cells, for the folds of ONE
+    matrix, without re-deriving everything from an n x n matrix per fold: the non-NA cells are listed
+    once; a fold drops its held-out cells from the list and rebuilds degrees, ordering, edge list and
+    start positions from what is left (same arithmetic in the same order as core.prepare_layout_call,
+    so the result is identical -- tests/test_host_driver.py)."""
+
+    def __init__(self, m: core.CodedMatrix):
+        self.m = m
+        n = self.n = m.values.shape[0]
+        non_na = ~np.isnan(m.values)
+        cols, rows = np.nonzero(non_na.T)            # column-major enumeration, as R's which()
+        self.rows, self.cols = rows.astype(np.int64), cols.astype(np.int64)
+        self.vals = m.values[rows, cols]
+        self.codes = m.codes[rows, cols].astype(np.int32)
+        self.pos_of = np.full(n * n, -1, dtype=np.int64)
+        self.pos_of[self.rows + self.cols * n] = np.arange(self.rows.shape[0])
+        self.zeroed = np.where(non_na, m.values, 0.0)   # NaN -> 0, the form np.nanmean sums
+        self.offdiag = ~np.eye(n, dtype=bool)
+        self.row_cnt = (non_na & self.offdiag).sum(axis=1)
+        self.col_cnt = (non_na & self.offdiag).sum(axis=0)
+
+    def _order(self, dr, dc):
+        """core.spectral_order of the matrix with cells (dr, dc) set to NA."""
+        n = self.n
+        z = self.zeroed.copy()
+        z[dr, dc] = 0.0
+        np.fill_diagonal(z, 0.0)
+        off = dr != dc
+        rc = self.row_cnt - np.bincount(dr[off], minlength=n)
+        cc = self.col_cnt - np.bincount(dc[off], minlength=n)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            avg = (z.sum(axis=1) / rc + z.sum(axis=0) / cc) / 2.0
+        avg[np.isnan(avg)] = 0.0
+        if int(np.sum(avg > 0)) > 1:
+            return np.argsort(avg, kind="stable")
+        return None
+
+    def fold(self, picks: np.ndarray, ndim: int, mapping_max_iter, k0, cooling_rate, c_repulsion,
+             relative_epsilon, convergence_counter, convergence_check_freq, preserve_order, rng):
+        """(SparseCall, (hold_i, hold_j, hold_truth)) for the fold holding out the linear
+        (column-major) cell indices `picks` and their mirrors."""
+        n = self.n
+        r, c = picks % n, picks // n
+        lin = np.unique(np.concatenate([r + c * n, c + r * n]))     # every cell once
+        at = self.pos_of[lin]
+        at = at[at >= 0]
+        keep = np.ones(self.rows.shape[0], dtype=bool)
+        keep[at] = False
+        dr, dc = self.rows[at], self.cols[at]
+        order = None
+        if n > 1 and not preserve_order:
+            order = self._order(dr, dc)
+        inv = np.arange(n)
+        if order is not None:
+            inv = np.empty(n, dtype=np.int64)
+            inv[order] = np.arange(n)
+        rows, cols = inv[self.rows[keep]], inv[self.cols[keep]]
+        vals, codes = self.vals[keep], self.codes[keep]
+        degrees = np.bincount(rows, minlength=n).astype(np.int32)
+        up = rows < cols
+        if not up.any():
+            raise ValueError("No valid off-diagonal measurements found in dissimilarity matrix")
+        er, ec, ev, ek = rows[up], cols[up], vals[up], codes[up]
+        srt = np.lexsort((er, ec))                                   # column-major scan
+        numeric = vals[codes == 0]
+        init_step = (numeric.max() if numeric.size else np.nan) / n
+        steps = rng.uniform(0.0, 2.0 * init_step, size=(int(ndim), n - 1)).T
+        init = np.vstack([np.zeros((1, int(ndim))), np.cumsum(steps, axis=0)])
+        names = self.m.names
+        if names is not None and order is not None:
+            names = [names[q] for q in order]
+        call = SparseCall(
+            initial_positions=np.ascontiguousarray(init, dtype=np.float64), degrees=degrees,
+            edge_i=er[srt].astype(np.int32), edge_j=ec[srt].astype(np.int32),
+            edge_dist=ev[srt].astype(np.float64), edge_thresh=ek[srt].astype(np.int32),
+            n_iter=int(mapping_max_iter), k0=float(k0), cooling_rate=float(cooling_rate),
+            c_repulsion=float(c_repulsion), relative_epsilon=float(relative_epsilon),
+            convergence_window=int(convergence_counter),
+            convergence_check_freq=int(convergence_check_freq), names=names, order=order)
+        # out-of-sample cells: held out AND numeric in the truth (as.numeric drops thresholds)
+        numeric_truth = self.codes[at] == 0
+        # error_calculator_comparison lines the prediction up with the truth BY NAME
+        # (R/error_metrics.R:100-112); an unnamed matrix is compared cell by cell as it comes back,
+        # i.e. in the reordered numbering -- reproduced
+        to_pred = inv if self.m.names is not None else np.arange(n)
+        hold = (to_pred[dr[numeric_truth]].astype(np.int32), to_pred[dc[numeric_truth]].astype(np.int32),
+                self.vals[at][numeric_truth].astype(np.float64))
+        return call, hold
+
+
 def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]], mapping_max_iter: int,
                      relative_epsilon: float, folds: int = 20, preserve_order: bool = False,
-                     rng: Optional[np.random.Generator] = None, precision: str = "f64"):
+                     rng: Optional[np.random.Generator] = None, precision: str = "f64",
+                     path: str = "sparse"):
     """`likelihood_function` for MANY parameter sets at once: all folds of all sets are relaxed
-    in ONE batched launch.  param_sets: dicts with N (ndim), k0, cooling_rate, c_repulsion.
+    in ONE batched launch, and the held-out cells are scored on the device (no est_distances, no
+    n x n arrays).  param_sets: dicts with N (ndim), k0, cooling_rate, c_repulsion.
+    path = "dense" runs the reference's own sequence per fold instead (masked n x n matrix ->
+    prepare_layout_call -> est_distances -> error_calculator_comparison): same folds, same start
+    positions, same pooled numbers; kept as the cross-check.
     Returns (list of result dicts, device_seconds, embeddings)."""
     rng = rng if rng is not None else _native.host_rng()
     if not hasattr(rng, "choice"):   # R-stream generator: fold sampling uses a NumPy stream seeded from it
@@ -90,26 +210,51 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     m = core.coded_matrix(dissimilarity_matrix)   # strings are parsed once, not once per fold
     if m is None:
         raise ValueError("dissimilarity_matrix must be a matrix")
-    calls, owners, inputs = [], [], []
+    if path not in ("sparse", "dense"):
+        raise ValueError("path must be 'sparse' or 'dense'")
+    builder = FoldBuilder(m) if path == "sparse" else None
+    calls, owners, inputs, holds = [], [], [], []
     for s_idx, ps in enumerate(param_sets):
         fold_sets = make_folds(m.values, folds, rng)
         n_pts = m.values.shape[0]
+        set_ok = True
+        if builder is not None:
+            try:    # the parameter checks of R/core.R:202-264, once per set instead of once per fold
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    core._validate(m, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"],
+                                   ps["c_repulsion"], relative_epsilon, 5, 3, None)
+            except ValueError:
+                set_ok = False
         for h in fold_sets:
-            masked = m.masked(h % n_pts, h // n_pts)
+            masked, hold = None, None
             try:
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    call = core.prepare_layout_call(masked, int(ps["N"]), mapping_max_iter, ps["k0"],
-                                                    ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
-                                                    5, None, False, 3, preserve_order, rng)
+                    if builder is None:
+                        masked = m.masked(h % n_pts, h // n_pts)
+                        call = core.prepare_layout_call(masked, int(ps["N"]), mapping_max_iter, ps["k0"],
+                                                        ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
+                                                        5, None, False, 3, preserve_order, rng)
+                    elif set_ok:
+                        call, hold = builder.fold(h, int(ps["N"]), mapping_max_iter, ps["k0"],
+                                                  ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
+                                                  5, 3, preserve_order, rng)
+                    else:
+                        call = None
             except ValueError:
                 call = None  # the reference's tryCatch turns a failed fold into an NA row
             calls.append(call)
             owners.append(s_idx)
             inputs.append(masked)
-    live = [c for c in calls if c is not None]
+            holds.append(hold)
+    live = [q for q, c in enumerate(calls) if c is not None]
     seeds = [int(rng.integers(0, 2 ** 63 - 1)) for _ in live]
-    results, secs = _native.optimize_layout_exact_batch(live, seeds=seeds, precision=precision) if live else ([], 0.0)
+    results, secs = ([], 0.0)
+    if live:
+        results, secs = _native.optimize_layout_exact_batch(
+            [calls[q] for q in live], seeds=seeds, precision=precision,
+            holdouts=[holds[q] for q in live] if builder is not None else None)
     it = iter(results)
     per_set: List[List[dict]] = [[] for _ in param_sets]
     for call, owner, masked in zip(calls, owners, inputs):
@@ -118,13 +263,17 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
         res = next(it)
         if isinstance(res, Exception):
             continue
-        p = res.positions
-        diff = p[:, None, :] - p[None, :, :]
-        est = np.sqrt((diff * diff).sum(-1))
-        err = error_calculator_comparison(est, m, masked, pred_names=call.names, true_names=m.names)
-        oe = err["OutSampleError"]
-        oe = oe[~np.isnan(oe)]
-        per_set[owner].append(dict(n_samples=int(oe.size), sum_abs_errors=float(np.abs(oe).sum()),
+        if builder is not None:
+            n_samples, sum_abs = int(res.info["holdout_count"]), float(res.info["holdout_sum_abs"])
+        else:
+            p = res.positions
+            diff = p[:, None, :] - p[None, :, :]
+            est = np.sqrt((diff * diff).sum(-1))
+            err = error_calculator_comparison(est, m, masked, pred_names=call.names, true_names=m.names)
+            oe = err["OutSampleError"]
+            oe = oe[~np.isnan(oe)]
+            n_samples, sum_abs = int(oe.size), float(np.abs(oe).sum())
+        per_set[owner].append(dict(n_samples=n_samples, sum_abs_errors=sum_abs,
                                    iter=res.iterations, converged=int(res.converged)))
     out = []
     for rows in per_set:
