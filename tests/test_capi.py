@@ -112,3 +112,42 @@ def test_too_few_points_message():
     with pytest.raises(_native.NativeError, match="Need at least 2 points for embedding"):
         _native.optimize_layout_exact_arrays(np.zeros((1, 2)), np.zeros((1, 1)), np.zeros((1, 1), np.int32),
                                              [0], [], [], [], [], 5, 1.0, 0.1, 0.1, 1e-4, 5, 3, seed=1)
+
+
+def test_struct_layout_matches_the_header(tmp_path):
+    """The ctypes twins of topolow_problem / topolow_result / topolow_options must have the C sizes."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "topolow_relax.h"\nint main(void){printf("%zu %zu %zu\\n",'
+                   'sizeof(topolow_problem), sizeof(topolow_result), sizeof(topolow_options));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(_native.TopolowProblem), C.sizeof(_native.TopolowResult),
+                     C.sizeof(_native.TopolowOptions)]
+
+
+def test_stage_kernel_awaits_its_lds_transfers_past_exactly_the_younger_loads():
+    """The stage kernel issues its direct-to-LDS transfers from inline asm and, before the chunk
+    barrier, waits for them with `s_waitcnt vmcnt(N)`, N = the target loads issued since (vmcnt counts
+    in issue order).  N is a template constant; the loads are the compiler's.  If the compiler ever
+    dropped or merged one of them the wait would be too weak (a transfer could still be in flight at
+    the barrier), so the ISA of every instantiation is checked: between the last transfer of the loop
+    body and the wait there must be exactly N `buffer_load_dwordx4`."""
+    import subprocess
+    csrc = os.path.join(ROOT, "topolow_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asm"], check=True, capture_output=True)
+    text = open(os.path.join(csrc, "topolow_relax.gfx950.s")).read()
+    names = re.findall(r"^(_ZN7topolow22slab_stage_pipe_kernel\w+):", text, re.M)
+    assert len(names) == 40                      # ndim 1..10 x {f32, f64} x {threshold, threshold-free}
+    for name in names:
+        start = text.index("\n" + name + ":")
+        body = text[start:text.index(".Lfunc_end", start)].split("\n")
+        waits = [q for q, l in enumerate(body) if "s_waitcnt vmcnt(" in l and "ASMSTART" in body[q - 1]]
+        counts = [int(re.search(r"vmcnt\((\d+)\)", body[q]).group(1)) for q in waits]
+        assert len(waits) == 2 and counts[0] == 0 and counts[1] > 0, (name, counts)   # prologue, loop
+        q = waits[1]
+        dma = max(i for i in range(q) if "global_load_lds_dwordx4" in body[i])
+        assert dma > waits[0]                     # the loop's own transfer, not the prologue's
+        younger = sum("buffer_load_dwordx4" in l for l in body[dma:q])
+        assert younger == counts[1], (name, younger, counts[1])
