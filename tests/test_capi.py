@@ -151,3 +151,7 @@ def test_stage_kernel_awaits_its_lds_transfers_past_exactly_the_younger_loads():
         assert dma > waits[0]                     # the loop's own transfer, not the prologue's
         younger = sum("buffer_load_dwordx4" in l for l in body[dma:q])
         assert younger == counts[1], (name, younger, counts[1])
+        # and no instantiation may spill registers (the threshold-carrying fp32 instance at ndim 10
+        # once did, inside the pair loop: 9x slower)
+        tail = text[text.index(".Lfunc_end", start):][:3000]
+        assert re.search(r"; ScratchSize: (\d+)", tail).group(1) == "0", name

@@ -261,8 +261,18 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
                        s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
                        s->rowflags.p, st, rg, iter1, k, s->c_rep);
   };
-  if (s->any_threshold) launch(&slab_stage_pipe_kernel<DIM, real, CFG, true>);
-  else launch(&slab_stage_pipe_kernel<DIM, real, CFG, false>);
+  if (s->any_threshold) {
+    // The instance that also carries the ">" / "<" classification needs more registers: from
+    // ndim 7 on it would spill inside the pair loop at a 5-wave budget (9x slower at ndim 10), so
+    // it is built for 4 waves per SIMD there and for 3 from ndim 9 (tests/test_capi.py checks that no
+    // instantiation uses scratch).
+    constexpr int kThrWaves = sizeof(real) == 4 ? (DIM >= 9 ? 3 : (DIM >= 7 ? 4 : 5)) : 1;
+    using CfgThr = StageCfg<CFG::THREADS, CFG::RPW, CFG::CHUNK, CFG::PRIO,
+                            CFG::MINWAVES < kThrWaves ? CFG::MINWAVES : kThrWaves>;
+    launch(&slab_stage_pipe_kernel<DIM, real, CfgThr, true>);
+  } else {
+    launch(&slab_stage_pipe_kernel<DIM, real, CFG, false>);
+  }
 }
 
 template <int DIM>
