@@ -249,6 +249,7 @@ def test_checks_beside_next_iteration_change_nothing(monkeypatch):
             s = _native.Session(700, 3, precision="f32")
             s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
             s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+            assert s.uses_dense_mae     # the MAE comes from the encoded block in every run
             s.set_positions(call.initial_positions)
             s.begin(n_iter, 6.0, 0.03, 0.01, 1e-3, window, freq, 5, 0)
             s.run()

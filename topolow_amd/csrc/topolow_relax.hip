@@ -762,7 +762,8 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
       if (owned) {
         DevBuf<unsigned long long> d_fp;
         d_fp.alloc(2);
-        HIP_TRY(hipMemset(d_fp.p, 0, 16));
+        // on the session's stream: it is non-blocking, a null-stream memset is not ordered with it
+        HIP_TRY(hipMemsetAsync(d_fp.p, 0, 16, s->stream));
         hipLaunchKernelGGL(upper_fingerprint_kernel, dim3(s->rows()), dim3(kThreads), 0, s->stream,
                            s->enc.p, s->n, s->row_begin, s->row_end, s->ld, s->dense_parity ? 1 : 0,
                            d_fp.p);
@@ -787,8 +788,9 @@ int topolow_session_set_positions(topolow_session* s, const double* positions, c
     upload_positions(s, positions, s->pos[0].p);
     // the other buffers need the same padding rows
     for (int b = 1; b < 3; ++b)
-      HIP_TRY(hipMemcpy(s->pos[b].p, s->pos[0].p, (size_t)s->pos_rows() * s->dim * s->real_size(),
-                        hipMemcpyDeviceToDevice));
+      HIP_TRY(hipMemcpyAsync(s->pos[b].p, s->pos[0].p, (size_t)s->pos_rows() * s->dim * s->real_size(),
+                             hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     s->held = -1;
   });
 }
