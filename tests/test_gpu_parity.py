@@ -530,3 +530,40 @@ def test_interrupt_callback_and_verbose(capfd):
     got = _native.optimize_layout_exact_arrays(*layout_call_args(call), True, seed=1, schedule="slab")
     out = capfd.readouterr().out
     assert "Points: 1200" in out and "Iter " in out and "topolow_relax[slab]" in out and got.iterations > 0
+
+
+# ----------------------------------------------------------------------------------------
+# BASELINE config 4 size (N = 50 000, ndim 3, 90 % missing) on one GPU: the row-sharded driver
+# (caller's stream, one stage per call, replicated controller) against the session's own loop
+# ----------------------------------------------------------------------------------------
+def test_config4_size_sharded_driver_equals_session_loop():
+    torch = pytest.importorskip("torch")
+    from topolow_amd import sharded
+    n, dim, iters = 50000, 3, 6
+    backend = sharded.HipBackend(n, dim, 0, n, 0)
+    n_edges, scale = sharded.load_synthetic_block(backend, n, 3, 0.9, 12345, 0, 1)
+    assert 0.09 * n * (n - 1) / 2 < n_edges < 0.11 * n * (n - 1) / 2
+    rng = np.random.Generator(np.random.PCG64(999))
+    init = np.zeros((n, dim))
+    init[1:] = np.cumsum(rng.uniform(0.0, 2.0 * scale / n, size=(n - 1, dim)), axis=0)
+    coll = sharded.Collectives(1)
+    a = sharded.relax_sharded(backend, coll, 0, 1, n, init, iters, 5.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 7, 0)
+    b = sharded.relax_sharded(backend, coll, 0, 1, n, init, iters, 5.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 7, 0)
+    assert np.array_equal(a.positions, b.positions) and a.final_mae == b.final_mae     # deterministic
+    assert np.isfinite(a.positions).all() and a.iterations == iters
+    # the same block through the session's own loop (own stream, checks beside the next iteration)
+    s = backend.session
+    torch.cuda.synchronize()
+    s.set_stream(None, external=False)
+    s.set_positions(init)
+    s.begin(iters, 5.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 7, 0)
+    s.run()
+    r = s.finish()
+    assert r.iterations == a.iterations
+    assert np.array_equal(r.positions, a.positions)
+    assert r.final_mae == pytest.approx(a.final_mae, rel=1e-6)
+    # the error has fallen well below that of the start positions
+    start = backend.to_device(init, n)
+    sm, cnt = s.edge_error(start.data_ptr())
+    assert cnt == n_edges and a.final_mae < 0.5 * sm / cnt
+    s.close()
