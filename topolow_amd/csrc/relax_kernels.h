@@ -12,6 +12,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "relax_common.h"
 
 namespace topolow {
@@ -65,6 +66,25 @@ __device__ __forceinline__ real wave_sum(real v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
+}
+
+// fp32 wave sum on the vector pipe alone (DPP lane permutations; __shfl_xor goes through LDS
+// hardware, ds_bpermute, with a round trip per step): quads, half rows, rows, then the row sums are
+// passed down the rows; the total is read from lane 63.  Fixed order, so deterministic; the value is
+// valid in every lane.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                 decltype(row_mask)::value, 0xf, true));
+  };
+  using std::integral_constant;
+  v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});   // row_half_mirror
+  v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});   // row_mirror
+  v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});   // row_bcast:15 -> rows 1, 3
+  v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});   // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // One encoded row as a buffer resource (wave-uniform, lives in 4 SGPRs): loads then need only a
@@ -476,7 +496,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
     real out[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {
-      const real total = wave_sum<real>(R.lane_sum(r, d));
+      real total;
+      if constexpr (sizeof(real) == 4) total = wave_sum_dpp(R.lane_sum(r, d));
+      else total = wave_sum<real>(R.lane_sum(r, d));
       out[d] = R.origin(r, d) - total;
       finite = finite && isfinite(out[d]);
     }
