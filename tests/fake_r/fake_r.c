@@ -1,0 +1,229 @@
+/* tests/fake_r/fake_r.c -- implementation of the R C API test double (Rinternals.h here) and the
+ * harness that plays R's part of `.Call("_topolow_optimize_layout_exact_cpp", ...)`:
+ *   harness <input file>
+ * The input file is text: first the options lines "opt <name> int|real|str <value>", then
+ *   n ndim n_edges n_iter convergence_window convergence_check_freq verbose
+ *   k0 cooling_rate c_repulsion relative_epsilon
+ * followed by the arrays in the order R/core.R:439-456 passes them (initial_positions, dissimilarity
+ * matrix ("Inf" allowed), threshold matrix, degrees, edge_i, edge_j, edge_dist, edge_thresh), all
+ * column-major.  The result list (or the R error) is printed as one JSON object.
+ * Test infrastructure only (tests/test_r_shim.py). */
+#include <math.h>
+#include <setjmp.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "R_ext/Rdynload.h"
+#include "Rinternals.h"
+
+static struct fake_sexp nil_obj = {NILSXP, 0, 0, 0, NULL, NULL};
+static struct fake_sexp names_sym = {CHARSXP, 5, 0, 0, (void*)"names", NULL};
+SEXP R_NilValue = &nil_obj;
+SEXP R_NamesSymbol = &names_sym;
+
+static jmp_buf error_jmp;
+static char error_msg[1024];
+static int protect_depth = 0;
+int fake_r_interrupt_after = 0;
+static int interrupt_calls = 0;
+static int interrupted = 0;
+
+SEXP Rf_allocVector(int type, R_xlen_t n) {
+  SEXP x = (SEXP)calloc(1, sizeof *x);
+  x->type = type;
+  x->length = n;
+  size_t el = type == REALSXP ? sizeof(double) : (type == STRSXP || type == VECSXP) ? sizeof(SEXP) : sizeof(int);
+  x->data = calloc(n ? (size_t)n : 1, el);
+  if (type == STRSXP || type == VECSXP)
+    for (R_xlen_t i = 0; i < n; ++i) ((SEXP*)x->data)[i] = R_NilValue;
+  return x;
+}
+SEXP Rf_allocMatrix(int type, int nrow, int ncol) {
+  SEXP x = Rf_allocVector(type, (R_xlen_t)nrow * ncol);
+  x->nrow = nrow;
+  x->ncol = ncol;
+  return x;
+}
+SEXP Rf_mkChar(const char* s) {
+  SEXP x = (SEXP)calloc(1, sizeof *x);
+  x->type = CHARSXP;
+  x->length = (R_xlen_t)strlen(s);
+  x->data = strdup(s);
+  return x;
+}
+SEXP Rf_mkString(const char* s) {
+  SEXP x = Rf_allocVector(STRSXP, 1);
+  SET_STRING_ELT(x, 0, Rf_mkChar(s));
+  return x;
+}
+SEXP Rf_ScalarLogical(int v) { SEXP x = Rf_allocVector(LGLSXP, 1); LOGICAL(x)[0] = v; return x; }
+SEXP Rf_ScalarInteger(int v) { SEXP x = Rf_allocVector(INTSXP, 1); INTEGER(x)[0] = v; return x; }
+SEXP Rf_ScalarReal(double v) { SEXP x = Rf_allocVector(REALSXP, 1); REAL(x)[0] = v; return x; }
+SEXP Rf_install(const char* name) { return Rf_mkChar(name); }
+
+static struct { char name[64]; SEXP value; } options[32];
+static int n_options = 0;
+static void set_option(const char* name, SEXP v) {
+  strncpy(options[n_options].name, name, 63);
+  options[n_options++].value = v;
+}
+void fake_r_set_option_int(const char* name, int v) { set_option(name, Rf_ScalarInteger(v)); }
+void fake_r_set_option_real(const char* name, double v) { set_option(name, Rf_ScalarReal(v)); }
+void fake_r_set_option_string(const char* name, const char* v) { set_option(name, Rf_mkString(v)); }
+SEXP Rf_GetOption1(SEXP tag) {
+  for (int i = 0; i < n_options; ++i)
+    if (strcmp(options[i].name, CHAR(tag)) == 0) return options[i].value;
+  return R_NilValue;
+}
+SEXP Rf_setAttrib(SEXP x, SEXP what, SEXP value) { if (what == R_NamesSymbol) x->names = value; return value; }
+SEXP Rf_getAttrib(SEXP x, SEXP what) { return (what == R_NamesSymbol && x->names) ? x->names : R_NilValue; }
+
+double* REAL(SEXP x) { return (double*)x->data; }
+int* INTEGER(SEXP x) { return (int*)x->data; }
+int* LOGICAL(SEXP x) { return (int*)x->data; }
+const char* CHAR(SEXP x) { return (const char*)x->data; }
+SEXP STRING_ELT(SEXP x, R_xlen_t i) { return ((SEXP*)x->data)[i]; }
+SEXP VECTOR_ELT(SEXP x, R_xlen_t i) { return ((SEXP*)x->data)[i]; }
+void SET_STRING_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP*)x->data)[i] = v; }
+SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP*)x->data)[i] = v; return v; }
+
+int Rf_length(SEXP x) { return (int)x->length; }
+R_xlen_t XLENGTH(SEXP x) { return x->length; }
+int Rf_nrows(SEXP x) { return x->ncol > 0 ? x->nrow : (int)x->length; }
+int Rf_ncols(SEXP x) { return x->ncol > 0 ? x->ncol : 1; }
+Rboolean Rf_isReal(SEXP x) { return x->type == REALSXP; }
+Rboolean Rf_isInteger(SEXP x) { return x->type == INTSXP; }
+Rboolean Rf_isString(SEXP x) { return x->type == STRSXP; }
+Rboolean Rf_isMatrix(SEXP x) { return x->ncol > 0; }
+int Rf_asInteger(SEXP x) { return x->type == REALSXP ? (int)REAL(x)[0] : INTEGER(x)[0]; }
+double Rf_asReal(SEXP x) { return x->type == REALSXP ? REAL(x)[0] : (double)INTEGER(x)[0]; }
+int Rf_asLogical(SEXP x) { return x->type == REALSXP ? REAL(x)[0] != 0.0 : INTEGER(x)[0] != 0; }
+
+SEXP Rf_protect(SEXP x) { ++protect_depth; return x; }
+void Rf_unprotect(int n) { protect_depth -= n; }
+int fake_r_protect_depth(void) { return protect_depth; }
+
+void Rf_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_msg, sizeof error_msg, fmt, ap);
+  va_end(ap);
+  longjmp(error_jmp, 1);
+}
+void Rf_onintr(void) { interrupted = 1; }
+/* an "interrupt" is a long jump out of R_CheckUserInterrupt, caught by R_ToplevelExec */
+static jmp_buf toplevel_jmp;
+static int in_toplevel = 0;
+void R_CheckUserInterrupt(void) {
+  ++interrupt_calls;
+  if (fake_r_interrupt_after > 0 && interrupt_calls >= fake_r_interrupt_after) {
+    if (in_toplevel) longjmp(toplevel_jmp, 1);
+    Rf_error("interrupt outside R_ToplevelExec");
+  }
+}
+Rboolean R_ToplevelExec(void (*fun)(void*), void* data) {
+  in_toplevel = 1;
+  if (setjmp(toplevel_jmp) != 0) { in_toplevel = 0; return FALSE; }
+  fun(data);
+  in_toplevel = 0;
+  return TRUE;
+}
+static int rng_open = 0;
+static unsigned long long rng_state = 0x9E3779B97F4A7C15ull;
+void GetRNGstate(void) { ++rng_open; }
+void PutRNGstate(void) { --rng_open; }
+double unif_rand(void) {
+  if (rng_open != 1) Rf_error("unif_rand outside GetRNGstate/PutRNGstate");
+  rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+  return (double)(rng_state >> 11) / 9007199254740992.0;
+}
+
+static DllInfo dll;
+int R_registerRoutines(DllInfo* info, const void* c, const R_CallMethodDef* call, const void* f, const void* e) {
+  (void)c; (void)f; (void)e;
+  info->call_routines = call;
+  return 1;
+}
+Rboolean R_useDynamicSymbols(DllInfo* info, Rboolean value) { info->use_dynamic_symbols = value; return TRUE; }
+
+/* ---------------------------------------------------------------------------------------------
+ * harness
+ * ------------------------------------------------------------------------------------------- */
+void R_init_topolow(DllInfo* dll);
+typedef SEXP (*call16)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
+
+static double read_num(FILE* f) {
+  char tok[64];
+  if (fscanf(f, "%63s", tok) != 1) { fprintf(stderr, "short input\n"); exit(2); }
+  if (strcmp(tok, "Inf") == 0) return INFINITY;
+  return strtod(tok, NULL);
+}
+static SEXP read_real(FILE* f, int nrow, int ncol) {
+  SEXP x = ncol > 0 ? Rf_allocMatrix(REALSXP, nrow, ncol) : Rf_allocVector(REALSXP, nrow);
+  for (R_xlen_t i = 0; i < x->length; ++i) REAL(x)[i] = read_num(f);
+  return x;
+}
+static SEXP read_int(FILE* f, int nrow, int ncol) {
+  SEXP x = ncol > 0 ? Rf_allocMatrix(INTSXP, nrow, ncol) : Rf_allocVector(INTSXP, nrow);
+  for (R_xlen_t i = 0; i < x->length; ++i) INTEGER(x)[i] = (int)read_num(f);
+  return x;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  FILE* f = fopen(argv[1], "r");
+  if (!f) return 2;
+  char word[64];
+  long at = ftell(f);
+  while (fscanf(f, "%63s", word) == 1 && strcmp(word, "opt") == 0) {
+    char name[64], kind[16], val[64];
+    if (fscanf(f, "%63s %15s %63s", name, kind, val) != 3) return 2;
+    if (strcmp(kind, "int") == 0) fake_r_set_option_int(name, atoi(val));
+    else if (strcmp(kind, "real") == 0) fake_r_set_option_real(name, atof(val));
+    else if (strcmp(name, "fake.interrupt_after") == 0) fake_r_interrupt_after = atoi(val);
+    else fake_r_set_option_string(name, val);
+    at = ftell(f);
+  }
+  fseek(f, at, SEEK_SET);
+  const int n = (int)read_num(f), ndim = (int)read_num(f), n_edges = (int)read_num(f), n_iter = (int)read_num(f);
+  const int window = (int)read_num(f), freq = (int)read_num(f), verbose = (int)read_num(f);
+  const double k0 = read_num(f), cool = read_num(f), c_rep = read_num(f), eps = read_num(f);
+  SEXP pos = read_real(f, n, ndim), D = read_real(f, n, n), T = read_int(f, n, n), deg = read_int(f, n, 0);
+  SEXP ei = read_int(f, n_edges, 0), ej = read_int(f, n_edges, 0), ed = read_real(f, n_edges, 0);
+  SEXP et = read_int(f, n_edges, 0);
+  fclose(f);
+
+  /* what useDynLib(topolow, .registration = TRUE) does: init, then look the routine up by name */
+  R_init_topolow(&dll);
+  call16 fn = NULL;
+  int arity = -1;
+  for (const R_CallMethodDef* m = dll.call_routines; m && m->name; ++m)
+    if (strcmp(m->name, "_topolow_optimize_layout_exact_cpp") == 0) { fn = (call16)m->fun; arity = m->numArgs; }
+  if (!fn || arity != 16 || dll.use_dynamic_symbols != FALSE) {
+    printf("{\"registration\": \"bad\"}\n");
+    return 1;
+  }
+  if (setjmp(error_jmp) != 0) {
+    printf("{\"error\": \"%s\", \"protect_depth\": %d, \"interrupted\": %d}\n", error_msg, protect_depth, interrupted);
+    return 0;
+  }
+  SEXP iter = Rf_ScalarInteger(n_iter);
+  SEXP sk0 = Rf_ScalarReal(k0), scool = Rf_ScalarReal(cool), scr = Rf_ScalarReal(c_rep), seps = Rf_ScalarReal(eps);
+  SEXP out = fn(pos, D, T, deg, ei, ej, ed, et, iter, sk0, scool, scr, seps, Rf_ScalarInteger(window),
+                Rf_ScalarInteger(freq), Rf_ScalarLogical(verbose));
+  printf("{\"names\": [");
+  SEXP names = Rf_getAttrib(out, R_NamesSymbol);
+  for (int i = 0; i < Rf_length(names); ++i) printf("%s\"%s\"", i ? ", " : "", CHAR(STRING_ELT(names, i)));
+  SEXP p = VECTOR_ELT(out, 0);
+  printf("], \"dim\": [%d, %d], \"positions\": [", Rf_nrows(p), Rf_ncols(p));
+  for (R_xlen_t i = 0; i < XLENGTH(p); ++i) printf("%s%.17g", i ? ", " : "", REAL(p)[i]);
+  printf("], \"converged\": %d, \"iterations\": %d, \"final_mae\": %.17g, \"final_k\": %.17g, "
+         "\"types\": [%d, %d, %d, %d, %d], \"protect_depth\": %d, \"interrupt_polls\": %d}\n",
+         LOGICAL(VECTOR_ELT(out, 1))[0], INTEGER(VECTOR_ELT(out, 2))[0], REAL(VECTOR_ELT(out, 3))[0],
+         REAL(VECTOR_ELT(out, 4))[0], VECTOR_ELT(out, 0)->type, VECTOR_ELT(out, 1)->type,
+         VECTOR_ELT(out, 2)->type, VECTOR_ELT(out, 3)->type, VECTOR_ELT(out, 4)->type, protect_depth,
+         interrupt_calls);
+  return 0;
+}
