@@ -573,3 +573,53 @@ def test_config4_size_sharded_driver_equals_session_loop():
     sm, cnt = s.edge_error(start.data_ptr())
     assert cnt == n_edges and a.final_mae < 0.5 * sm / cnt
     s.close()
+
+
+def test_full_size_with_thresholds_config_3b():
+    """BASELINE config 3b: config 3 with 10 % of the measured pairs censored (">" at the 90th
+    percentile).  The threshold-carrying kernel instance at full size: deterministic, its reported
+    MAE is the oracle's edge error of the returned positions (threshold rule included), and one stage
+    agrees with the slab model."""
+    n, dim = 10000, 5
+    prob = synthetic.make_problem(n, latent_dim=dim, missing=0.7, seed=12345)
+    D = prob.dissimilarity
+    iu, ju = np.triu_indices(n, 1)
+    vals = D[iu, ju]
+    rng = np.random.default_rng(1)
+    sel = ~np.isnan(vals) & (rng.random(iu.size) < 0.1)
+    q90 = np.nanquantile(vals, 0.9)
+    m = core.CodedMatrix(D.copy(), np.zeros((n, n), dtype=np.int32), None, True)
+    m.values[iu[sel], ju[sel]] = np.minimum(vals[sel], q90)
+    m.values[ju[sel], iu[sel]] = m.values[iu[sel], ju[sel]]
+    m.codes[iu[sel], ju[sel]] = 1
+    m.codes[ju[sel], iu[sel]] = 1
+    init = synthetic.initial_positions(D, dim, 12345)
+    call = core.prepare_layout_call(m, dim, 9, 5.0, 0.01, 0.01, 1e-4, 5, init, False, 3, True)
+    assert int((call.edge_thresh == 1).sum()) == int(sel.sum()) > 1_000_000
+    s = _native.Session(n, dim, precision="f32")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert s.uses_dense_mae
+
+    def run(iters, stages):
+        s.set_positions(call.initial_positions)
+        s.begin(iters, 5.0, 0.01, 0.01, 1e-4, 5, 3, 21, stages)
+        s.run()
+        return s.finish()
+
+    a, b = run(9, 0), run(9, 0)
+    assert np.array_equal(a.positions, b.positions) and a.final_mae == b.final_mae
+    sm, cnt = orc.edge_error(a.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert a.final_mae == pytest.approx(sm / cnt, rel=2e-5) and np.isfinite(a.positions).all()
+    # one stage against the model on the thresholded rows
+    s.set_positions(call.initial_positions)
+    s.begin(1, 5.0, 0.01, 0.01, 1e-4, 5, 1, 11, 4)
+    s.run()
+    got = s.get_positions()
+    pos = call.initial_positions
+    for rg in _native.slab_plan(n, 4, 11, 0):
+        pos = slab_model.stage(pos, call.dissimilarity_matrix, call.threshold_matrix, call.degrees,
+                               [r for r in rg.reshape(2, 2) if r[1] > r[0]], 5.0, 0.01, "f64")
+    scale = np.abs(pos - call.initial_positions).max()
+    assert np.abs(got - pos).max() <= 3e-4 * scale
+    s.close()
