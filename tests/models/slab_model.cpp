@@ -22,7 +22,9 @@ void stage(const real* pin, real* pout, int n, int dim, const double* D, const i
            const double* g, const int32_t* ranges, int n_ranges, double k, double c_rep) {
   // pin/pout: row-major n x dim.  D/T: column-major n x n as R passes them; the cell of the
   // unordered pair {i,c} is the upper-triangle one, D[min + max*n] (src/optimization.cpp:217).
-#pragma omp parallel for schedule(dynamic, 16)
+  // at most 8 threads, and none for small problems: test machines report hundreds of hardware
+  // threads behind a CPU quota, where a default-sized team turns a millisecond loop into seconds
+#pragma omp parallel for schedule(dynamic, 16) num_threads(8) if (n >= 1024)
   for (int i = 0; i < n; ++i) {
     real acc[16];
     for (int d = 0; d < dim; ++d) acc[d] = 0;

@@ -25,7 +25,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/topolow_relax.h"
@@ -611,6 +613,36 @@ inline bool gs_edges_well_formed(const GsProblem& p) {
   return std::adjacent_find(key.begin(), key.end()) == key.end();
 }
 
+// Host-side loops over the problems of a batch are independent: spread them over a few threads (a
+// sweep stages thousands of small problems; sorting and packing them serially took as long as the
+// kernel).  `fn(b)` may throw GsHipError; the first one is rethrown on the caller's thread.
+template <typename Fn>
+void gs_parallel_for(int count, Fn fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int workers = std::max(1, std::min({count / 16, (int)(hw ? hw : 1), 16}));
+  if (workers <= 1) {
+    for (int b = 0; b < count; ++b) fn(b);
+    return;
+  }
+  std::atomic<int> next{0};
+  std::atomic<bool> failed{false};
+  GsHipError first{TOPOLOW_OK, ""};
+  std::vector<std::thread> pool;
+  for (int w = 0; w < workers; ++w) {
+    pool.emplace_back([&] {
+      for (int b = next.fetch_add(1); b < count && !failed.load(); b = next.fetch_add(1)) {
+        try {
+          fn(b);
+        } catch (const GsHipError& e) {
+          if (!failed.exchange(true)) first = e;
+        }
+      }
+    });
+  }
+  for (auto& t : pool) t.join();
+  if (failed.load()) throw first;
+}
+
 // Host/device staging of a whole batch: every array of every problem lives in ONE host buffer that
 // goes to the device with one copy (thousands of small embeddings per launch otherwise spend their
 // time in hipMalloc / hipMemcpy calls); positions sit together at the front so they come back with
@@ -650,22 +682,27 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
     // batch qualifies (edge list == matrix, or edge list given as the matrix; n <= 2048; table
     // within the LDS budget)
     bool sparse = getenv("TOPOLOW_GS_DENSE") == nullptr;
-    for (int b = 0; b < count; ++b) {
-      const GsProblem& p = pbs[b];
-      if (p.dim != dim) throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "batch must share ndim"};
-      if (p.n < 2) throw GsHipError{TOPOLOW_ERR_TOO_FEW_POINTS, "Need at least 2 points for embedding"};
-      if ((p.D == nullptr) != (p.T == nullptr))
-        throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "dissimilarity and threshold matrices come together"};
-      if (p.D == nullptr && !gs_edges_well_formed(p))
-        throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT,
-                         "edge list that stands for the matrix needs 0 <= i < j < n, finite targets, no pair twice"};
-      for (long long e = 0; e < p.n_hold; ++e)
-        if (p.hold_i[e] < 0 || p.hold_i[e] >= p.n || p.hold_j[e] < 0 || p.hold_j[e] >= p.n)
-          throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "holdout pair out of range"};
-      if (sparse)
-        sparse = p.n <= 2048 && p.n_edges > 0 && p.n_edges < 65535 &&
-                 gs_lds_bytes(p.n, dim, sizeof(real), p.n_edges) <= kGsSparseLdsBudget &&
-                 (p.D == nullptr || gs_edges_match_matrix(p));
+    {
+      std::vector<char> ok_sparse(count, 1);
+      const bool want_sparse = sparse;
+      gs_parallel_for(count, [&](int b) {
+        const GsProblem& p = pbs[b];
+        if (p.dim != dim) throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "batch must share ndim"};
+        if (p.n < 2) throw GsHipError{TOPOLOW_ERR_TOO_FEW_POINTS, "Need at least 2 points for embedding"};
+        if ((p.D == nullptr) != (p.T == nullptr))
+          throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "dissimilarity and threshold matrices come together"};
+        if (p.D == nullptr && !gs_edges_well_formed(p))
+          throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT,
+                           "edge list that stands for the matrix needs 0 <= i < j < n, finite targets, no pair twice"};
+        for (long long e = 0; e < p.n_hold; ++e)
+          if (p.hold_i[e] < 0 || p.hold_i[e] >= p.n || p.hold_j[e] < 0 || p.hold_j[e] >= p.n)
+            throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "holdout pair out of range"};
+        if (want_sparse)
+          ok_sparse[b] = p.n <= 2048 && p.n_edges > 0 && p.n_edges < 65535 &&
+                         gs_lds_bytes(p.n, dim, sizeof(real), p.n_edges) <= kGsSparseLdsBudget &&
+                         (p.D == nullptr || gs_edges_match_matrix(p));
+      });
+      for (int b = 0; b < count; ++b) sparse = sparse && ok_sparse[b];
     }
     // ---- layout ----
     struct Off {
@@ -713,7 +750,7 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
     }
     A.commit();
     // ---- fill ----
-    for (int b = 0; b < count; ++b) {
+    gs_parallel_for(count, [&](int b) {
       const GsProblem& p = pbs[b];
       const Off& o = off[b];
       const size_t nn = (size_t)p.n * p.n, ne = (size_t)p.n_edges;
@@ -773,7 +810,7 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
         std::memcpy(A.host<int>(o.hj), p.hold_j, (size_t)p.n_hold * 4);
         std::memcpy(A.host<double>(o.ht), p.hold_truth, (size_t)p.n_hold * 8);
       }
-    }
+    });
     GS_TRY(hipMalloc((void**)&d_scratch, best_total ? best_total : 256));
     A.upload();   // device addresses exist from here on; the problem table follows with its own copy
     {
