@@ -669,19 +669,42 @@ class GsArena {
   unsigned char* dev_ = nullptr;
 };
 
+// One grid of the exact-GS kernel (all problems share ndim and precision), in three steps so that
+// several grids can be staged, run side by side on their own streams, and collected afterwards.
+struct GsBatchBase {
+  virtual ~GsBatchBase() {}
+  virtual void stage(const GsProblem* pbs, int count) = 0;   // validate, pack, upload
+  virtual void launch(hipStream_t st) = 0;
+  virtual int collect(GsResult* res, char* errbuf, size_t errlen) = 0;   // after the stream is idle
+};
+
 template <typename real>
-int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* device_seconds,
-                   char* errbuf, size_t errlen) {
-  int rc = TOPOLOW_OK;
+class GsBatch : public GsBatchBase {
+  struct Off {
+    size_t pos, gplus, tm = 0, cm = 0, ei = 0, ej = 0, et = 0, ec, roff = 0, ecol = 0, erow = 0, etgt = 0,
+           hi = 0, hj = 0, ht = 0, best;
+  };
+  const GsProblem* pbs = nullptr;
+  int count = 0, dim = 0, n_max = 0;
+  size_t lds_max = 0, o_out = 0, o_prob = 0;
+  bool sparse = false;
+  std::vector<Off> off;
+  GsArena A;
   unsigned char* d_scratch = nullptr;   // best snapshots: device only
-  try {
-    const int dim = pbs[0].dim;
-    size_t lds_max = 0;
-    int n_max = 0;
+
+ public:
+  ~GsBatch() override { (void)hipFree(d_scratch); }
+
+  void stage(const GsProblem* pbs_, int count_) override {
+    pbs = pbs_;
+    count = count_;
+    dim = pbs[0].dim;
+    lds_max = 0;
+    n_max = 0;
     // one kernel instance per launch: the LDS-resident table is used when EVERY problem of the
     // batch qualifies (edge list == matrix, or edge list given as the matrix; n <= 2048; table
     // within the LDS budget)
-    bool sparse = getenv("TOPOLOW_GS_DENSE") == nullptr;
+    sparse = getenv("TOPOLOW_GS_DENSE") == nullptr;
     {
       std::vector<char> ok_sparse(count, 1);
       const bool want_sparse = sparse;
@@ -705,17 +728,11 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
       for (int b = 0; b < count; ++b) sparse = sparse && ok_sparse[b];
     }
     // ---- layout ----
-    struct Off {
-      size_t pos, gplus, tm = 0, cm = 0, ei = 0, ej = 0, et = 0, ec, roff = 0, ecol = 0, erow = 0, etgt = 0,
-             hi = 0, hj = 0, ht = 0, best;
-    };
-    std::vector<Off> off(count);
-    GsArena A;
+    off.assign(count, Off{});
     size_t best_total = 0;
     for (int b = 0; b < count; ++b) off[b].pos = A.reserve((size_t)pbs[b].n * dim * sizeof(real));
-    const size_t pos_region = A.reserve(0);
-    const size_t o_out = A.reserve(sizeof(GsOut) * count);
-    const size_t o_prob = A.reserve(sizeof(GsDev<real>) * count);
+    o_out = A.reserve(sizeof(GsOut) * count);
+    o_prob = A.reserve(sizeof(GsDev<real>) * count);
     for (int b = 0; b < count; ++b) {
       const GsProblem& p = pbs[b];
       const size_t lds = gs_lds_bytes(p.n, dim, sizeof(real), sparse ? p.n_edges : 0);
@@ -840,29 +857,24 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
       }
       GS_TRY(hipMemcpy(A.dev<GsDev<real>>(o_prob), h.data(), sizeof(GsDev<real>) * count, hipMemcpyHostToDevice));
     }
+  }
+
+  void launch(hipStream_t st) override {
     const GsDev<real>* d_problems = A.dev<GsDev<real>>(o_prob);
     int threads = (((n_max + 1) / 2) + 63) & ~63;
     threads = std::max(128, std::min(1024, threads));
-    hipEvent_t e0, e1;
-    GS_TRY(hipEventCreate(&e0));
-    GS_TRY(hipEventCreate(&e1));
-    GS_TRY(hipEventRecord(e0, 0));
     switch (dim) {
-#define GS_CASE(D) case D: gs_launch<D, real>(d_problems, count, threads, lds_max, sparse, 0); break;
+#define GS_CASE(D) case D: gs_launch<D, real>(d_problems, count, threads, lds_max, sparse, st); break;
       GS_CASE(1) GS_CASE(2) GS_CASE(3) GS_CASE(4) GS_CASE(5) GS_CASE(6) GS_CASE(7) GS_CASE(8)
       GS_CASE(9) GS_CASE(10)
 #undef GS_CASE
       default: throw GsHipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 10"};
     }
-    GS_TRY(hipEventRecord(e1, 0));
-    GS_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    GS_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (device_seconds) *device_seconds = ms * 1e-3;
+  }
+
+  int collect(GsResult* res, char* errbuf, size_t errlen) override {
+    int rc = TOPOLOW_OK;
     A.download_front(o_out + sizeof(GsOut) * count);   // positions and results
-    (void)pos_region;
     const GsOut* outs = A.host<GsOut>(o_out);
     for (int b = 0; b < count; ++b) {
       const GsProblem& p = pbs[b];
@@ -881,19 +893,41 @@ int gs_run_batch_t(const GsProblem* pbs, GsResult* res, int count, double* devic
       res[b].nonfinite_iter = o.nonfinite_iter;
       res[b].hold_sum = o.hold_sum; res[b].hold_count = (long long)o.hold_cnt;
     }
+    return rc;
+  }
+};
+
+inline GsBatchBase* gs_new_batch(int precision) {
+  if (precision == TOPOLOW_PRECISION_F32) return new GsBatch<float>();
+  return new GsBatch<double>();
+}
+
+// One grid, start to finish (the single-embedding path of topolow_optimize_layout_exact).
+inline int gs_run_batch(const GsProblem* pbs, GsResult* res, int count, int precision,
+                        double* device_seconds, char* errbuf, size_t errlen) {
+  int rc = TOPOLOW_OK;
+  GsBatchBase* batch = gs_new_batch(precision);
+  try {
+    batch->stage(pbs, count);
+    hipEvent_t e0, e1;
+    GS_TRY(hipEventCreate(&e0));
+    GS_TRY(hipEventCreate(&e1));
+    GS_TRY(hipEventRecord(e0, 0));
+    batch->launch(0);
+    GS_TRY(hipEventRecord(e1, 0));
+    GS_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GS_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (device_seconds) *device_seconds = ms * 1e-3;
+    rc = batch->collect(res, errbuf, errlen);
   } catch (const GsHipError& e) {
     if (errbuf && errlen) snprintf(errbuf, errlen, "%s", e.msg.c_str());
     rc = e.code;
   }
-  (void)hipFree(d_scratch);
+  delete batch;
   return rc;
-}
-
-inline int gs_run_batch(const GsProblem* pbs, GsResult* res, int count, int precision,
-                        double* device_seconds, char* errbuf, size_t errlen) {
-  if (precision == TOPOLOW_PRECISION_F32)
-    return gs_run_batch_t<float>(pbs, res, count, device_seconds, errbuf, errlen);
-  return gs_run_batch_t<double>(pbs, res, count, device_seconds, errbuf, errlen);
 }
 
 }  // namespace topolow

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <deque>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/topolow_relax.h"
@@ -1077,49 +1078,96 @@ int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow
   int rc_all = TOPOLOW_OK;
   const int rc = guarded(errbuf, errlen, [&] {
     select_device(device);
-    // the kernel is instantiated per ndim: run one grid per distinct ndim
+    // The kernel is instantiated per ndim: one grid per distinct ndim.  The grids are independent,
+    // so they are staged one after another and then run SIDE BY SIDE on their own streams (a sweep
+    // over ndim 2..10 would otherwise run nine under-filled grids back to back, each with its own
+    // tail of slow embeddings).
     std::vector<int> dims;
     for (int b = 0; b < count; ++b) {
       if (problems[b].n < 2) throw HipError{TOPOLOW_ERR_TOO_FEW_POINTS, "Need at least 2 points for embedding"};
       if (std::find(dims.begin(), dims.end(), problems[b].ndim) == dims.end()) dims.push_back(problems[b].ndim);
     }
-    for (int dim : dims) {
+    struct Grid {
       std::vector<GsProblem> pbs;
       std::vector<GsResult> res;
       std::vector<int> idx;
-      for (int b = 0; b < count; ++b) {
-        const topolow_problem& p = problems[b];
-        if (p.ndim != dim) continue;
-        GsProblem g;
-        g.initial_positions = p.initial_positions; g.D = p.dissimilarity_matrix; g.T = p.threshold_matrix;
-        g.degrees = p.degrees; g.edge_i = p.edge_i; g.edge_j = p.edge_j; g.edge_dist = p.edge_dist;
-        g.edge_thresh = p.edge_thresh; g.n_edges = p.n_edges; g.n = p.n; g.dim = p.ndim;
-        g.n_iter = p.n_iter; g.window = p.convergence_window; g.check_freq = p.convergence_check_freq;
-        g.k0 = p.k0; g.cooling = p.cooling_rate; g.c_rep = p.c_repulsion; g.eps = p.relative_epsilon;
-        g.seed = p.seed;
-        g.hold_i = p.holdout_i; g.hold_j = p.holdout_j; g.hold_truth = p.holdout_truth;
-        g.n_hold = (p.holdout_i && p.holdout_j && p.holdout_truth) ? p.n_holdout : 0;
-        GsResult r;
-        r.positions = results[b].positions_out;
-        pbs.push_back(g); res.push_back(r); idx.push_back(b);
+      std::unique_ptr<GsBatchBase> batch;
+      hipStream_t stream = nullptr;
+      hipEvent_t done = nullptr;
+    };
+    std::vector<Grid> grids(dims.size());
+    hipEvent_t start = nullptr;
+    auto release = [&] {
+      for (Grid& g : grids) {
+        if (g.stream) { (void)hipStreamSynchronize(g.stream); (void)hipStreamDestroy(g.stream); }
+        if (g.done) (void)hipEventDestroy(g.done);
+        g.batch.reset();
+      }
+      if (start) (void)hipEventDestroy(start);
+    };
+    try {
+      for (size_t q = 0; q < dims.size(); ++q) {
+        Grid& g = grids[q];
+        for (int b = 0; b < count; ++b) {
+          const topolow_problem& p = problems[b];
+          if (p.ndim != dims[q]) continue;
+          GsProblem pb;
+          pb.initial_positions = p.initial_positions; pb.D = p.dissimilarity_matrix; pb.T = p.threshold_matrix;
+          pb.degrees = p.degrees; pb.edge_i = p.edge_i; pb.edge_j = p.edge_j; pb.edge_dist = p.edge_dist;
+          pb.edge_thresh = p.edge_thresh; pb.n_edges = p.n_edges; pb.n = p.n; pb.dim = p.ndim;
+          pb.n_iter = p.n_iter; pb.window = p.convergence_window; pb.check_freq = p.convergence_check_freq;
+          pb.k0 = p.k0; pb.cooling = p.cooling_rate; pb.c_rep = p.c_repulsion; pb.eps = p.relative_epsilon;
+          pb.seed = p.seed;
+          pb.hold_i = p.holdout_i; pb.hold_j = p.holdout_j; pb.hold_truth = p.holdout_truth;
+          pb.n_hold = (p.holdout_i && p.holdout_j && p.holdout_truth) ? p.n_holdout : 0;
+          GsResult r;
+          r.positions = results[b].positions_out;
+          g.pbs.push_back(pb); g.res.push_back(r); g.idx.push_back(b);
+        }
+        g.batch.reset(gs_new_batch(prec));
+        g.batch->stage(g.pbs.data(), (int)g.pbs.size());
+        HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&g.done));
+      }
+      HIP_TRY(hipEventCreate(&start));
+      HIP_TRY(hipEventRecord(start, grids[0].stream));
+      for (Grid& g : grids) {
+        HIP_TRY(hipStreamWaitEvent(g.stream, start, 0));
+        g.batch->launch(g.stream);
+        HIP_TRY(hipEventRecord(g.done, g.stream));
       }
       double secs = 0.0;
-      char local_err[256];
-      local_err[0] = 0;
-      const int rcb = gs_run_batch(pbs.data(), res.data(), (int)pbs.size(), prec, &secs, local_err,
-                                   sizeof local_err);
-      if (rcb != TOPOLOW_OK && rcb != TOPOLOW_ERR_NONFINITE) throw HipError{rcb, local_err};
-      if (device_seconds) *device_seconds += secs;
-      for (size_t q = 0; q < idx.size(); ++q) {
-        topolow_result& o = results[idx[q]];
-        o.final_mae = res[q].final_mae; o.final_k = res[q].final_k; o.converged = res[q].converged;
-        o.iterations = res[q].iterations; o.iterations_run = res[q].iters_run; o.n_checks = res[q].n_checks;
-        o.error_code = res[q].nonfinite_iter ? TOPOLOW_ERR_NONFINITE : TOPOLOW_OK;
-        o.error_iteration = res[q].nonfinite_iter;
-        o.holdout_sum_abs = res[q].hold_sum;
-        o.holdout_count = res[q].hold_count;
+      for (Grid& g : grids) {
+        HIP_TRY(hipEventSynchronize(g.done));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, start, g.done));
+        secs = std::max(secs, (double)ms * 1e-3);
       }
+      if (device_seconds) *device_seconds = secs;
+      for (Grid& g : grids) {
+        char local_err[256];
+        local_err[0] = 0;
+        const int rcb = g.batch->collect(g.res.data(), local_err, sizeof local_err);
+        if (rcb != TOPOLOW_OK && rcb != TOPOLOW_ERR_NONFINITE) throw HipError{rcb, local_err};
+        for (size_t q = 0; q < g.idx.size(); ++q) {
+          topolow_result& o = results[g.idx[q]];
+          const GsResult& r = g.res[q];
+          o.final_mae = r.final_mae; o.final_k = r.final_k; o.converged = r.converged;
+          o.iterations = r.iterations; o.iterations_run = r.iters_run; o.n_checks = r.n_checks;
+          o.error_code = r.nonfinite_iter ? TOPOLOW_ERR_NONFINITE : TOPOLOW_OK;
+          o.error_iteration = r.nonfinite_iter;
+          o.holdout_sum_abs = r.hold_sum;
+          o.holdout_count = r.hold_count;
+        }
+      }
+    } catch (const GsHipError& e) {
+      release();
+      throw HipError{e.code, e.msg};
+    } catch (...) {
+      release();
+      throw;
     }
+    release();
   });
   return rc != TOPOLOW_OK ? rc : rc_all;
 }
