@@ -142,6 +142,33 @@ int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow
                                         int32_t count, int32_t precision, int32_t device,
                                         double* device_seconds, char* errbuf, size_t errlen);
 
+/* Host-side helper of the batched CV evaluator: one fold's problem from the list of the full
+ * matrix's non-NA cells, i.e. what the reference obtains per fold by masking the held-out cells
+ * (R/adaptive_sampling.R:2600-2640) and re-running euclidean_embedding's pre-processing
+ * (R/core.R:269-436) on the n x n matrix.  No device work.  Cells are listed in column-major order
+ * (as R's which()); `pos_of` maps a linear column-major index to its cell or -1; `by_row`/`row_ptr`
+ * list the same cells row by row (columns ascending).  `picks`: held-out linear indices (their
+ * mirrors are held out too).  Outputs are caller-allocated: order n (order[0] = -1: input order
+ * kept), degrees n, edges and holdout up to n_cells entries; `numeric_max` = largest value among the
+ * remaining unprefixed cells (the scale of the random-walk start, R/core.R:407-415). */
+typedef struct topolow_cell_list {
+  int32_t n, reserved;
+  int64_t n_cells;
+  const int32_t* row;
+  const int32_t* col;
+  const double* value;      /* threshold prefix stripped */
+  const int32_t* code;      /* 0 none, 1 ">", -1 "<" */
+  const int64_t* pos_of;    /* n * n */
+  const int64_t* by_row;    /* n_cells */
+  const int64_t* row_ptr;   /* n + 1 */
+} topolow_cell_list;
+
+int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_t n_picks,
+                    int32_t preserve_order, int32_t named, int32_t* order, int32_t* degrees,
+                    int32_t* edge_i, int32_t* edge_j, double* edge_dist, int32_t* edge_thresh,
+                    int64_t* n_edges, int32_t* holdout_i, int32_t* holdout_j, double* holdout_truth,
+                    int64_t* n_holdout, double* numeric_max);
+
 /* Replaces `as.matrix(stats::dist(positions))` (reference R/core.R:474):
  * positions n x ndim float64 column-major (host) -> est_distances n x n float64 (host). */
 int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,

@@ -125,7 +125,8 @@ def _coded_random(n, seed, named):
     return core.CodedMatrix(d, codes, names, True)
 
 
-@pytest.mark.parametrize("source", ["hiv", "random_named", "random_unnamed"])
+@pytest.mark.parametrize("source", ["hiv", "random_named", "random_unnamed", "random_named_7", "random_named_150",
+                                    "random_unnamed_290"])
 def test_fold_builder_equals_the_dense_preparation(source):
     """cv.FoldBuilder (cell list, no n x n work per fold) must hand the kernel exactly what
     core.prepare_layout_call builds from the masked matrix, and its holdout list must be the
@@ -134,17 +135,29 @@ def test_fold_builder_equals_the_dense_preparation(source):
         rows = list(csv.DictReader(open(os.path.join(GOLD, "hiv_distances.csv"))))
         m = core.coded_matrix(antigenic.titers_list_to_matrix(rows, "Virus", "virusYear", "Antibody", None,
                                                               "distance", sort=True))
-    else:
-        m = _coded_random(41, 5, source == "random_named")
+    else:   # sizes on both sides of NumPy's pairwise-summation block limits (8, 128)
+        size = int(source.rsplit("_", 1)[1]) if source[-1].isdigit() else 41
+        m = _coded_random(size, 5 + size, "unnamed" not in source)
     n = m.values.shape[0]
     fb = cv.FoldBuilder(m)
     folds = cv.make_folds(m.values, 4, np.random.default_rng(3))
     assert len(folds) == 4
+    mine = fb.folds(4, np.random.default_rng(3))       # the cell-list version draws the same cells
+    assert len(mine) == 4 and all(np.array_equal(a, b) for a, b in zip(folds, mine))
     for q, h in enumerate(folds):
         r1, r2 = np.random.default_rng(100 + q), np.random.default_rng(100 + q)
         masked = m.masked(h % n, h // n)
         dense = core.prepare_layout_call(masked, 3, 50, 2.0, 0.02, 0.01, 1e-4, 5, None, False, 3, False, r1)
-        sparse, hold = fb.fold(h, 3, 50, 2.0, 0.02, 0.01, 1e-4, 5, 3, False, r2)
+        sparse, hold = fb.fold_numpy(h, 3, 50, 2.0, 0.02, 0.01, 1e-4, 5, 3, False, r2)
+        # ... and the library routine (host code of libtopolow_relax.so) equals the NumPy one
+        lib_call, lib_hold = fb.fold(h, 3, 50, 2.0, 0.02, 0.01, 1e-4, 5, 3, False, np.random.default_rng(100 + q))
+        assert (lib_call.order is None) == (sparse.order is None)
+        if sparse.order is not None:
+            assert np.array_equal(lib_call.order, sparse.order)
+        assert lib_call.names == sparse.names
+        for f in ("initial_positions", "degrees", "edge_i", "edge_j", "edge_dist", "edge_thresh"):
+            assert np.array_equal(getattr(lib_call, f), getattr(sparse, f)), f
+        assert all(np.array_equal(a, b) for a, b in zip(lib_hold, hold))
         assert (dense.order is None) == (sparse.order is None)
         if dense.order is not None:
             assert np.array_equal(dense.order, sparse.order)
@@ -162,5 +175,7 @@ def test_fold_builder_equals_the_dense_preparation(source):
     d2 = core.prepare_layout_call(m.masked(folds[0] % n, folds[0] // n), 2, 50, 2.0, 0.02, 0.01, 1e-4, 5, None,
                                   False, 3, True, np.random.default_rng(1))
     s2, _ = fb.fold(folds[0], 2, 50, 2.0, 0.02, 0.01, 1e-4, 5, 3, True, np.random.default_rng(1))
+    s3, _ = fb.fold_numpy(folds[0], 2, 50, 2.0, 0.02, 0.01, 1e-4, 5, 3, True, np.random.default_rng(1))
+    assert np.array_equal(s2.edge_dist, s3.edge_dist) and np.array_equal(s2.degrees, s3.degrees)
     assert s2.order is None and np.array_equal(d2.edge_i, s2.edge_i) and np.array_equal(d2.degrees, s2.degrees)
     assert np.array_equal(d2.initial_positions, s2.initial_positions)

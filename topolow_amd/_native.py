@@ -63,6 +63,14 @@ class TopolowProblem(C.Structure):
                 ("holdout_truth", C.POINTER(C.c_double)), ("n_holdout", C.c_int64)]
 
 
+class TopolowCellList(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("n_cells", C.c_int64),
+                ("row", C.POINTER(C.c_int32)), ("col", C.POINTER(C.c_int32)),
+                ("value", C.POINTER(C.c_double)), ("code", C.POINTER(C.c_int32)),
+                ("pos_of", C.POINTER(C.c_int64)), ("by_row", C.POINTER(C.c_int64)),
+                ("row_ptr", C.POINTER(C.c_int64))]
+
+
 class TopolowResult(C.Structure):
     _fields_ = [("positions_out", C.POINTER(C.c_double)), ("final_mae", C.c_double),
                 ("final_k", C.c_double), ("converged", C.c_int32), ("iterations", C.c_int32),
@@ -126,6 +134,7 @@ def load() -> C.CDLL:
     lib.topolow_optimize_layout_exact_batch.argtypes = [C.POINTER(TopolowProblem), C.POINTER(TopolowResult),
                                                         C.c_int32, C.c_int32, C.c_int32, dp, C.c_char_p,
                                                         C.c_size_t]
+    lib.topolow_cv_fold.restype = C.c_int
     lib.topolow_est_distances.restype = C.c_int
     lib.topolow_est_distances.argtypes = [dp, C.c_int32, C.c_int32, dp, C.c_int32, C.c_char_p,
                                           C.c_size_t]
@@ -369,6 +378,48 @@ def optimize_layout_exact_batch(calls, seeds=None, precision="f64", device=-1, h
                                              holdout_sum_abs=float(r.holdout_sum_abs),
                                              holdout_count=int(r.holdout_count))))
     return results, float(secs.value)
+
+
+class CellList:
+    """The non-NA cells of a matrix in the form `topolow_cv_fold` reads (include/topolow_relax.h)."""
+
+    def __init__(self, n, rows, cols, values, codes, pos_of):
+        self.n = int(n)
+        self.rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self.cols = np.ascontiguousarray(cols, dtype=np.int32)
+        self.values = np.ascontiguousarray(values, dtype=np.float64)
+        self.codes = np.ascontiguousarray(codes, dtype=np.int32)
+        self.pos_of = np.ascontiguousarray(pos_of, dtype=np.int64)
+        self.by_row = np.ascontiguousarray(np.lexsort((self.cols, self.rows)), dtype=np.int64)
+        counts = np.bincount(self.rows, minlength=self.n)
+        self.row_ptr = np.ascontiguousarray(np.concatenate([[0], np.cumsum(counts)]), dtype=np.int64)
+        c = self.c = TopolowCellList()
+        c.n, c.n_cells = self.n, int(self.rows.shape[0])
+        c.row, c.col, c.value, c.code = _ip(self.rows), _ip(self.cols), _dp(self.values), _ip(self.codes)
+        i64 = C.POINTER(C.c_int64)
+        c.pos_of, c.by_row, c.row_ptr = (self.pos_of.ctypes.data_as(i64), self.by_row.ctypes.data_as(i64),
+                                         self.row_ptr.ctypes.data_as(i64))
+
+
+def cv_fold(cells: CellList, picks, preserve_order: bool, named: bool):
+    """One fold's problem from the cell list (host-side helper of the CV evaluator).  Returns
+    (order or None, degrees, edge_i, edge_j, edge_dist, edge_thresh, hold_i, hold_j, hold_truth,
+    numeric_max)."""
+    lib = load()
+    picks = np.ascontiguousarray(picks, dtype=np.int64)
+    n, m = cells.n, int(cells.rows.shape[0])
+    order, deg = np.empty(n, np.int32), np.empty(n, np.int32)
+    ei, ej, ed, et = np.empty(m, np.int32), np.empty(m, np.int32), np.empty(m, np.float64), np.empty(m, np.int32)
+    hi, hj, ht = np.empty(m, np.int32), np.empty(m, np.int32), np.empty(m, np.float64)
+    ne, nh, vmax = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+    rc = lib.topolow_cv_fold(C.byref(cells.c), picks.ctypes.data_as(C.POINTER(C.c_int64)), int(picks.shape[0]),
+                             int(bool(preserve_order)), int(bool(named)), _ip(order), _ip(deg), _ip(ei), _ip(ej),
+                             _dp(ed), _ip(et), C.byref(ne), _ip(hi), _ip(hj), _dp(ht), C.byref(nh), C.byref(vmax))
+    if rc != OK:
+        raise NativeError(rc, "topolow_cv_fold failed")
+    e, h = int(ne.value), int(nh.value)
+    return (None if order[0] < 0 else order.astype(np.int64), deg, ei[:e].copy(), ej[:e].copy(), ed[:e].copy(),
+            et[:e].copy(), hi[:h].copy(), hj[:h].copy(), ht[:h].copy(), float(vmax.value))
 
 
 def est_distances(positions) -> np.ndarray:

@@ -23,6 +23,7 @@
 #include "../../include/topolow_relax.h"
 #include "relax_common.h"
 #include "relax_kernels.h"
+#include "relax_fold.h"
 #include "relax_gs.h"
 #include "relax_tilegs.h"
 
@@ -1173,6 +1174,23 @@ int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow
 }
 
 // ---- post metric -----------------------------------------------------------------------
+int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_t n_picks,
+                    int32_t preserve_order, int32_t named, int32_t* order, int32_t* degrees,
+                    int32_t* edge_i, int32_t* edge_j, double* edge_dist, int32_t* edge_thresh,
+                    int64_t* n_edges, int32_t* holdout_i, int32_t* holdout_j, double* holdout_truth,
+                    int64_t* n_holdout, double* numeric_max) {
+  if (!cells || (!picks && n_picks > 0) || !order || !degrees || !edge_i || !edge_j || !edge_dist ||
+      !edge_thresh || !n_edges || !holdout_i || !holdout_j || !holdout_truth || !n_holdout || !numeric_max)
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  try {
+    return fold_problem(cells, picks, n_picks, preserve_order, named, order, degrees, edge_i, edge_j,
+                        edge_dist, edge_thresh, n_edges, holdout_i, holdout_j, holdout_truth, n_holdout,
+                        numeric_max);
+  } catch (const std::bad_alloc&) {
+    return TOPOLOW_ERR_HIP;
+  }
+}
+
 int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
                           double* est_distances, int32_t device, char* errbuf, size_t errlen) {
   if (!positions || !est_distances || n < 1 || ndim < 1) return TOPOLOW_ERR_BAD_ARGUMENT;

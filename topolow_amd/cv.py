@@ -123,6 +123,28 @@ class FoldBuilder:
         self.offdiag = ~np.eye(n, dtype=bool)
         self.row_cnt = (non_na & self.offdiag).sum(axis=1)
         self.col_cnt = (non_na & self.offdiag).sum(axis=0)
+        self._cells = None          # the library's view of the list, built on first use
+
+    def folds(self, folds: int, rng: np.random.Generator):
+        """`make_folds` on the cell list: the same draws from the same stream (the pool handed to
+        rng.choice is the same array), without an n x n pass per fold."""
+        n = self.n
+        lin = self.rows + self.cols * n                  # ascending: the list is in column-major order
+        alive = np.ones(lin.shape[0], dtype=bool)
+        holdout_size = int(lin.shape[0]) // (folds * 2)
+        out = []
+        for _ in range(folds):
+            avail = lin[alive]
+            if avail.size < holdout_size:
+                warnings.warn("Could not create all folds due to data sparsity. Using fewer folds.")
+                break
+            pick = rng.choice(avail, size=holdout_size, replace=False)
+            out.append(pick)
+            r, c = pick % n, pick // n
+            alive[self.pos_of[pick]] = False
+            mirror = self.pos_of[c + r * n]
+            alive[mirror[mirror >= 0]] = False
+        return out
 
     def _order(self, dr, dc):
         """core.spectral_order of the matrix with cells (dr, dc) set to NA."""
@@ -143,7 +165,34 @@ class FoldBuilder:
     def fold(self, picks: np.ndarray, ndim: int, mapping_max_iter, k0, cooling_rate, c_repulsion,
              relative_epsilon, convergence_counter, convergence_check_freq, preserve_order, rng):
         """(SparseCall, (hold_i, hold_j, hold_truth)) for the fold holding out the linear
-        (column-major) cell indices `picks` and their mirrors."""
+        (column-major) cell indices `picks` and their mirrors.  The list work runs in the library's
+        host code (`topolow_cv_fold`, topolow_amd/csrc/relax_fold.h); `fold_numpy` is the same thing
+        in NumPy and the two are tested to agree to the last bit."""
+        n = self.n
+        if self._cells is None:
+            self._cells = _native.CellList(n, self.rows, self.cols, self.vals, self.codes, self.pos_of)
+        order, degrees, ei, ej, ed, et, hi, hj, ht, vmax = _native.cv_fold(
+            self._cells, picks, preserve_order, self.m.names is not None)
+        if ei.shape[0] == 0:
+            raise ValueError("No valid off-diagonal measurements found in dissimilarity matrix")
+        init_step = vmax / n
+        steps = rng.uniform(0.0, 2.0 * init_step, size=(int(ndim), n - 1)).T
+        init = np.vstack([np.zeros((1, int(ndim))), np.cumsum(steps, axis=0)])
+        names = self.m.names
+        if names is not None and order is not None:
+            names = [names[q] for q in order]
+        call = SparseCall(
+            initial_positions=np.ascontiguousarray(init, dtype=np.float64), degrees=degrees,
+            edge_i=ei, edge_j=ej, edge_dist=ed, edge_thresh=et,
+            n_iter=int(mapping_max_iter), k0=float(k0), cooling_rate=float(cooling_rate),
+            c_repulsion=float(c_repulsion), relative_epsilon=float(relative_epsilon),
+            convergence_window=int(convergence_counter),
+            convergence_check_freq=int(convergence_check_freq), names=names, order=order)
+        return call, (hi, hj, ht)
+
+    def fold_numpy(self, picks: np.ndarray, ndim: int, mapping_max_iter, k0, cooling_rate, c_repulsion,
+                   relative_epsilon, convergence_counter, convergence_check_freq, preserve_order, rng):
+        """`fold` in NumPy (the cross-check of the library routine)."""
         n = self.n
         r, c = picks % n, picks // n
         lin = np.unique(np.concatenate([r + c * n, c + r * n]))     # every cell once
@@ -214,15 +263,20 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
         raise ValueError("path must be 'sparse' or 'dense'")
     builder = FoldBuilder(m) if path == "sparse" else None
     calls, owners, inputs, holds = [], [], [], []
+    tiny = core.CodedMatrix(np.array([[0.0, 1.0], [1.0, 0.0]]), np.zeros((2, 2), dtype=np.int32))
+    if builder is not None:      # the matrix half of R/core.R:202-264 once; per set only the parameters
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            core._validate(m, 2, 1, 1.0, 0.5, 1.0, 1.0, 1, 1, None)
     for s_idx, ps in enumerate(param_sets):
-        fold_sets = make_folds(m.values, folds, rng)
+        fold_sets = builder.folds(folds, rng) if builder is not None else make_folds(m.values, folds, rng)
         n_pts = m.values.shape[0]
         set_ok = True
         if builder is not None:
             try:    # the parameter checks of R/core.R:202-264, once per set instead of once per fold
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    core._validate(m, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"],
+                    core._validate(tiny, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"],
                                    ps["c_repulsion"], relative_epsilon, 5, 3, None)
             except ValueError:
                 set_ok = False
