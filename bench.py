@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--points", dest="n", type=int, default=0, help="override the number of points (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--stages", type=int, default=0, help="fixed slab stages (0 = adaptive)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="multi-GPU mode: independent config-3 embeddings per GPU (weak scaling, "
