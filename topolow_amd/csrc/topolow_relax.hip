@@ -259,9 +259,19 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
   g_stamps.arm(blocks);
 #endif
   auto launch = [&](auto kern) {
+    // falling issue priority only when every workgroup of the grid is resident at once
+    static int resident_per_cu = 0, cus = 0;     // per instantiation (the lambda is one per kernel)
+    if (resident_per_cu == 0) {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+      cus = prop.multiProcessorCount;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_per_cu, kern, CFG::THREADS, 0));
+      if (resident_per_cu < 1) resident_per_cu = 1;
+    }
+    const int falling = blocks <= resident_per_cu * cus ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), 0, s->stream, s->enc.p, s->ld,
                        s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
-                       s->rowflags.p, st, rg, iter1, k, s->c_rep);
+                       s->rowflags.p, st, rg, iter1, k, s->c_rep, falling);
   };
   if (s->any_threshold) {
     // The instance that also carries the ">" / "<" classification needs more registers: from
