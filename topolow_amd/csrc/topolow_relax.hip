@@ -258,17 +258,17 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
 #ifdef TOPOLOW_TUNING
   g_stamps.arm(blocks);
 #endif
-  auto launch = [&](auto kern) {
+  auto launch = [&](auto kern, int which) {
     // falling issue priority only when every workgroup of the grid is resident at once
-    static int resident_per_cu = 0, cus = 0;     // per instantiation (the lambda is one per kernel)
-    if (resident_per_cu == 0) {
+    static int resident[2] = {0, 0};     // workgroups of this (ndim, precision) kernel a device holds
+    if (resident[which] == 0) {          // [0] threshold-free instance, [1] threshold-carrying one
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-      cus = prop.multiProcessorCount;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_per_cu, kern, CFG::THREADS, 0));
-      if (resident_per_cu < 1) resident_per_cu = 1;
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CFG::THREADS, 0));
+      resident[which] = std::max(1, per_cu) * prop.multiProcessorCount;
     }
-    const int falling = blocks <= resident_per_cu * cus ? 1 : 0;
+    const int falling = blocks <= resident[which] ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), 0, s->stream, s->enc.p, s->ld,
                        s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
                        s->rowflags.p, st, rg, iter1, k, s->c_rep, falling);
@@ -281,9 +281,9 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
     constexpr int kThrWaves = sizeof(real) == 4 ? (DIM >= 9 ? 3 : (DIM >= 7 ? 4 : 5)) : 1;
     using CfgThr = StageCfg<CFG::THREADS, CFG::RPW, CFG::CHUNK, CFG::PRIO,
                             CFG::MINWAVES < kThrWaves ? CFG::MINWAVES : kThrWaves>;
-    launch(&slab_stage_pipe_kernel<DIM, real, CfgThr, true>);
+    launch(&slab_stage_pipe_kernel<DIM, real, CfgThr, true>, 1);
   } else {
-    launch(&slab_stage_pipe_kernel<DIM, real, CFG, false>);
+    launch(&slab_stage_pipe_kernel<DIM, real, CFG, false>, 0);
   }
 }
 
