@@ -623,3 +623,22 @@ def test_full_size_with_thresholds_config_3b():
     scale = np.abs(pos - call.initial_positions).max()
     assert np.abs(got - pos).max() <= 3e-4 * scale
     s.close()
+
+
+def test_repeated_calls_do_not_leak_device_memory():
+    """A drop-in is called thousands of times from one R session (Euclidify): every call creates
+    and destroys its device state (buffers, two streams, events).  Device memory must come back."""
+    torch = pytest.importorskip("torch")
+    call, _ = _random_problem(300, 3, 0.6, seed=5, thresholds=0.1, n_iter=6)
+    args = layout_call_args(call)
+    _native.optimize_layout_exact_arrays(*args, seed=1, schedule="slab")      # warm-up: library, context
+    _native.optimize_layout_exact_arrays(*args, seed=1, schedule="gs")
+    torch.cuda.synchronize()
+    free0, _total = torch.cuda.mem_get_info()
+    for q in range(150):
+        _native.optimize_layout_exact_arrays(*args, seed=q, schedule="slab")
+        _native.optimize_layout_exact_arrays(*args, seed=q, schedule="gs")
+    _native.optimize_layout_exact_batch([call] * 40, seeds=list(range(40)))
+    torch.cuda.synchronize()
+    free1, _total = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 * 1024 * 1024, (free0, free1)
