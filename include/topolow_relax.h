@@ -49,13 +49,22 @@ typedef struct topolow_options {
   int32_t slab_stages;  /* 0 = adaptive: max(4, pow2ceil(k/2.5)) per check interval */
   int32_t device;       /* HIP device ordinal; -1 = current device */
   int32_t gs_max_n;     /* AUTO switches to the slab schedule above this n; 0 = default */
-  int32_t reserved[5];
+  int32_t n_devices;    /* > 1 (or a non-NULL `devices`): ONE embedding row-block sharded over
+                           devices[0..n_devices) -- see topolow_optimize_layout_exact_sharded */
+  int32_t reserved[4];
   /* Polled every 50 iterations like Rcpp::checkUserInterrupt() in the reference
    * (src/optimization.cpp:364); a non-zero return abandons the run with TOPOLOW_ERR_INTERRUPTED
-   * after device memory has been released.  NULL = never.  (Multi-workgroup schedules only: the
-   * one-workgroup GS kernel is a single launch.) */
+   * after device memory has been released.  NULL = never. */
   int32_t (*interrupt_cb)(void* user);
   void* interrupt_user;
+  /* Sink of the `verbose` lines (the reference prints them with Rcpp::Rcout,
+   * src/optimization.cpp:183-188,298-301,334-336,351-353): called with one NUL-terminated line
+   * (newline included) at a time, on the calling thread.  NULL = stdout.  The R shim maps it to
+   * Rprintf so the lines obey sink() and the console. */
+  void (*print_cb)(const char* line, void* user);
+  void* print_user;
+  const int32_t* devices;   /* n_devices HIP ordinals; an ordinal may repeat (several row blocks on
+                               one GPU).  NULL with n_devices > 1: ordinals 0..n_devices-1 */
 } topolow_options;
 
 /* Run statistics, filled by topolow_optimize_layout_exact when `stats` is non-NULL. */
@@ -163,6 +172,11 @@ typedef struct topolow_cell_list {
   const int64_t* row_ptr;   /* n + 1 */
 } topolow_cell_list;
 
+/* Fills the index arrays of a cell list from its (row, col) columns, listed in column-major order:
+ * pos_of (n*n, -1 where no cell), by_row (n_cells), row_ptr (n+1).  No device work. */
+int topolow_cell_list_index(int32_t n, int64_t n_cells, const int32_t* row, const int32_t* col,
+                            int64_t* pos_of, int64_t* by_row, int64_t* row_ptr);
+
 int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_t n_picks,
                     int32_t preserve_order, int32_t named, int32_t* order, int32_t* degrees,
                     int32_t* edge_i, int32_t* edge_j, double* edge_dist, int32_t* edge_thresh,
@@ -234,6 +248,10 @@ int topolow_session_sync(topolow_session* s, int32_t* iterations_run, int32_t* s
 int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* converged,
                            int32_t* iterations, double* final_mae, double* final_k,
                            char* errbuf, size_t errlen);
+/* The convergence checks of the current run so far: 3 doubles per check (iteration, MAE, k after
+ * cooling) -- the values behind the reference's verbose lines (src/optimization.cpp:298-301).
+ * Waits for the enqueued work.  *n_checks = checks recorded; at most max_checks are copied. */
+int topolow_session_check_trace(topolow_session* s, double* out, int32_t max_checks, int32_t* n_checks);
 /* Per-kernel timing for roofline accounting: while enabled, every slab-stage launch and
  * every convergence check is bracketed by HIP events on the session stream.
  * topolow_session_profile waits for the stream, returns the summed durations (ms) and launch

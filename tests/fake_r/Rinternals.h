@@ -33,6 +33,10 @@ typedef struct fake_sexp {
 
 extern SEXP R_NilValue;
 extern SEXP R_NamesSymbol;
+extern SEXP R_GlobalEnv;
+extern SEXP R_UnboundValue;
+extern SEXP R_NaString;
+#define TYPEOF(x) ((x)->type)
 
 SEXP Rf_allocVector(int type, R_xlen_t n);
 SEXP Rf_allocMatrix(int type, int nrow, int ncol);
@@ -41,6 +45,10 @@ SEXP Rf_mkString(const char* s);
 SEXP Rf_ScalarLogical(int v);
 SEXP Rf_ScalarInteger(int v);
 SEXP Rf_ScalarReal(double v);
+SEXP Rf_ScalarString(SEXP ch);
+SEXP Rf_findVarInFrame(SEXP env, SEXP sym);   /* knows `.Random.seed` of the global environment only */
+char* R_alloc(size_t n, int size);
+void Rprintf(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 SEXP Rf_install(const char* name);
 SEXP Rf_GetOption1(SEXP tag);
 SEXP Rf_setAttrib(SEXP x, SEXP what, SEXP value);
@@ -86,6 +94,9 @@ void fake_r_set_option_int(const char* name, int v);
 void fake_r_set_option_real(const char* name, double v);
 void fake_r_set_option_string(const char* name, const char* v);
 int fake_r_protect_depth(void);
+void fake_r_set_random_seed(int present);   /* give the global environment a `.Random.seed` */
+int fake_r_unif_rand_calls(void);
+unsigned long long fake_r_random_seed_hash(void);
 extern int fake_r_interrupt_after;   /* > 0: R_CheckUserInterrupt "interrupts" at that call */
 
 #ifdef __cplusplus

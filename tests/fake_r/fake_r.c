@@ -20,8 +20,18 @@
 
 static struct fake_sexp nil_obj = {NILSXP, 0, 0, 0, NULL, NULL};
 static struct fake_sexp names_sym = {CHARSXP, 5, 0, 0, (void*)"names", NULL};
+static struct fake_sexp global_env = {NILSXP, 0, 0, 0, NULL, NULL};
+static struct fake_sexp unbound = {NILSXP, 0, 0, 0, NULL, NULL};
+static struct fake_sexp na_string = {CHARSXP, 2, 0, 0, (void*)"NA", NULL};
 SEXP R_NilValue = &nil_obj;
 SEXP R_NamesSymbol = &names_sym;
+SEXP R_GlobalEnv = &global_env;
+SEXP R_UnboundValue = &unbound;
+SEXP R_NaString = &na_string;
+static SEXP random_seed = NULL;
+static int unif_calls = 0;
+static char printed[1 << 16];
+static size_t printed_len = 0;
 
 static jmp_buf error_jmp;
 static char error_msg[1024];
@@ -62,6 +72,31 @@ SEXP Rf_ScalarLogical(int v) { SEXP x = Rf_allocVector(LGLSXP, 1); LOGICAL(x)[0]
 SEXP Rf_ScalarInteger(int v) { SEXP x = Rf_allocVector(INTSXP, 1); INTEGER(x)[0] = v; return x; }
 SEXP Rf_ScalarReal(double v) { SEXP x = Rf_allocVector(REALSXP, 1); REAL(x)[0] = v; return x; }
 SEXP Rf_install(const char* name) { return Rf_mkChar(name); }
+SEXP Rf_ScalarString(SEXP ch) { SEXP x = Rf_allocVector(STRSXP, 1); SET_STRING_ELT(x, 0, ch); return x; }
+SEXP Rf_findVarInFrame(SEXP env, SEXP sym) {
+  if (env == R_GlobalEnv && strcmp(CHAR(sym), ".Random.seed") == 0 && random_seed != NULL) return random_seed;
+  return R_UnboundValue;
+}
+char* R_alloc(size_t n, int size) { return (char*)calloc(n ? n : 1, (size_t)size); }
+void Rprintf(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  const int w = vsnprintf(printed + printed_len, sizeof printed - printed_len, fmt, ap);
+  va_end(ap);
+  if (w > 0) printed_len += (size_t)w < sizeof printed - printed_len ? (size_t)w : sizeof printed - printed_len - 1;
+}
+void fake_r_set_random_seed(int present) {
+  if (!present) { random_seed = NULL; return; }
+  random_seed = Rf_allocVector(INTSXP, 626);   /* Mersenne-Twister: kind, mti, 624 words */
+  unsigned long long z = 0x1234abcdull * (unsigned)present;
+  for (int i = 0; i < 626; ++i) { z = z * 6364136223846793005ull + 1442695040888963407ull; INTEGER(random_seed)[i] = (int)(z >> 33); }
+}
+int fake_r_unif_rand_calls(void) { return unif_calls; }
+unsigned long long fake_r_random_seed_hash(void) {
+  unsigned long long h = 1469598103934665603ull;
+  if (random_seed) for (int i = 0; i < 626; ++i) h = (h ^ (unsigned)INTEGER(random_seed)[i]) * 1099511628211ull;
+  return h;
+}
 
 static struct { char name[64]; SEXP value; } options[32];
 static int n_options = 0;
@@ -136,6 +171,7 @@ void GetRNGstate(void) { ++rng_open; }
 void PutRNGstate(void) { --rng_open; }
 double unif_rand(void) {
   if (rng_open != 1) Rf_error("unif_rand outside GetRNGstate/PutRNGstate");
+  ++unif_calls;
   rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
   return (double)(rng_state >> 11) / 9007199254740992.0;
 }
@@ -171,22 +207,104 @@ static SEXP read_int(FILE* f, int nrow, int ncol) {
   return x;
 }
 
+static void print_json_string(const char* t) {
+  putchar('"');
+  for (; *t; ++t) {
+    if (*t == '"' || *t == '\\') { putchar('\\'); putchar(*t); }
+    else if (*t == '\n') fputs("\\n", stdout);
+    else putchar(*t);
+  }
+  putchar('"');
+}
+static void print_vec(SEXP v) {
+  printf("[");
+  if (v != R_NilValue)
+    for (R_xlen_t i = 0; i < XLENGTH(v); ++i) {
+      if (v->type == REALSXP) printf("%s%.17g", i ? ", " : "", REAL(v)[i]);
+      else printf("%s%d", i ? ", " : "", INTEGER(v)[i]);
+    }
+  printf("]");
+}
+static void print_tail(void) {
+  printf("\"protect_depth\": %d, \"interrupt_polls\": %d, \"unif_rand_calls\": %d, \"random_seed_hash\": \"%llu\", "
+         "\"printed\": ", protect_depth, interrupt_calls, unif_calls, fake_r_random_seed_hash());
+  print_json_string(printed);
+  printf("}\n");
+}
+static DL_FUNC find_routine(const char* name, int arity) {
+  for (const R_CallMethodDef* m = dll.call_routines; m && m->name; ++m)
+    if (strcmp(m->name, name) == 0 && m->numArgs == arity) return m->fun;
+  return NULL;
+}
+
+/* Input: option lines, then an optional "mode <single|batch K H|cvfold>" line (default single).
+ *   single : the 16-argument call (header comment).
+ *   batch  : the same input, sent K times through _topolow_optimize_layout_exact_batch as a list of
+ *            argument lists; calls with an odd index pass NULL matrices (the edge list is the matrix);
+ *            the first H edges are scored as hold-out pairs.
+ *   cvfold : "n m n_picks preserve_order named" then row, col, value, code, picks. */
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   FILE* f = fopen(argv[1], "r");
   if (!f) return 2;
   char word[64];
   long at = ftell(f);
-  while (fscanf(f, "%63s", word) == 1 && strcmp(word, "opt") == 0) {
+  char mode[16] = "single";
+  int batch_k = 0, batch_h = 0;
+  while (fscanf(f, "%63s", word) == 1 && (strcmp(word, "opt") == 0 || strcmp(word, "mode") == 0)) {
+    if (strcmp(word, "mode") == 0) {
+      if (fscanf(f, "%15s", mode) != 1) return 2;
+      if (strcmp(mode, "batch") == 0 && fscanf(f, "%d %d", &batch_k, &batch_h) != 2) return 2;
+      at = ftell(f);
+      continue;
+    }
     char name[64], kind[16], val[64];
     if (fscanf(f, "%63s %15s %63s", name, kind, val) != 3) return 2;
-    if (strcmp(kind, "int") == 0) fake_r_set_option_int(name, atoi(val));
-    else if (strcmp(kind, "real") == 0) fake_r_set_option_real(name, atof(val));
+    if (strcmp(name, "fake.random_seed") == 0) fake_r_set_random_seed(atoi(val));
     else if (strcmp(name, "fake.interrupt_after") == 0) fake_r_interrupt_after = atoi(val);
+    else if (strcmp(kind, "int") == 0) fake_r_set_option_int(name, atoi(val));
+    else if (strcmp(kind, "real") == 0) fake_r_set_option_real(name, atof(val));
+    else if (strcmp(kind, "ints") == 0) {   /* comma-separated integer vector */
+      int vals[64], nv = 0;
+      for (char* tok = strtok(val, ","); tok && nv < 64; tok = strtok(NULL, ",")) vals[nv++] = atoi(tok);
+      SEXP v = Rf_allocVector(INTSXP, nv);
+      memcpy(INTEGER(v), vals, sizeof(int) * (size_t)nv);
+      set_option(name, v);
+    }
     else fake_r_set_option_string(name, val);
     at = ftell(f);
   }
   fseek(f, at, SEEK_SET);
+  /* what useDynLib(topolow, .registration = TRUE) does: init, then look the routines up by name */
+  R_init_topolow(&dll);
+  if (dll.use_dynamic_symbols != FALSE) { printf("{\"registration\": \"bad\"}\n"); return 1; }
+
+  if (strcmp(mode, "cvfold") == 0) {
+    typedef SEXP (*call8)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
+    call8 fn = (call8)find_routine("_topolow_cv_fold", 8);
+    if (!fn) { printf("{\"registration\": \"bad\"}\n"); return 1; }
+    const int n = (int)read_num(f), m = (int)read_num(f), np = (int)read_num(f);
+    const int preserve = (int)read_num(f), named = (int)read_num(f);
+    SEXP row = read_int(f, m, 0), col = read_int(f, m, 0), val = read_real(f, m, 0), code = read_int(f, m, 0);
+    SEXP picks = read_real(f, np, 0);
+    fclose(f);
+    if (setjmp(error_jmp) != 0) {
+      printf("{\"error\": \"%s\", ", error_msg);
+      print_tail();
+      return 0;
+    }
+    SEXP out = fn(row, col, val, code, Rf_ScalarInteger(n), picks, Rf_ScalarLogical(preserve), Rf_ScalarLogical(named));
+    SEXP names = Rf_getAttrib(out, R_NamesSymbol);
+    printf("{");
+    for (int i = 0; i < Rf_length(out); ++i) {
+      printf("\"%s\": ", CHAR(STRING_ELT(names, i)));
+      print_vec(VECTOR_ELT(out, i));
+      printf(", ");
+    }
+    print_tail();
+    return 0;
+  }
+
   const int n = (int)read_num(f), ndim = (int)read_num(f), n_edges = (int)read_num(f), n_iter = (int)read_num(f);
   const int window = (int)read_num(f), freq = (int)read_num(f), verbose = (int)read_num(f);
   const double k0 = read_num(f), cool = read_num(f), c_rep = read_num(f), eps = read_num(f);
@@ -194,36 +312,70 @@ int main(int argc, char** argv) {
   SEXP ei = read_int(f, n_edges, 0), ej = read_int(f, n_edges, 0), ed = read_real(f, n_edges, 0);
   SEXP et = read_int(f, n_edges, 0);
   fclose(f);
+  SEXP iter = Rf_ScalarInteger(n_iter);
+  SEXP sk0 = Rf_ScalarReal(k0), scool = Rf_ScalarReal(cool), scr = Rf_ScalarReal(c_rep), seps = Rf_ScalarReal(eps);
 
-  /* what useDynLib(topolow, .registration = TRUE) does: init, then look the routine up by name */
-  R_init_topolow(&dll);
-  call16 fn = NULL;
-  int arity = -1;
-  for (const R_CallMethodDef* m = dll.call_routines; m && m->name; ++m)
-    if (strcmp(m->name, "_topolow_optimize_layout_exact_cpp") == 0) { fn = (call16)m->fun; arity = m->numArgs; }
-  if (!fn || arity != 16 || dll.use_dynamic_symbols != FALSE) {
+  if (strcmp(mode, "batch") == 0) {
+    typedef SEXP (*call1)(SEXP);
+    call1 fn = (call1)find_routine("_topolow_optimize_layout_exact_batch", 1);
+    if (!fn) { printf("{\"registration\": \"bad\"}\n"); return 1; }
+    SEXP calls = Rf_allocVector(VECSXP, batch_k);
+    SEXP hi = Rf_allocVector(INTSXP, batch_h), hj = Rf_allocVector(INTSXP, batch_h), ht = Rf_allocVector(REALSXP, batch_h);
+    for (int q = 0; q < batch_h; ++q) { INTEGER(hi)[q] = INTEGER(ei)[q]; INTEGER(hj)[q] = INTEGER(ej)[q]; REAL(ht)[q] = REAL(ed)[q]; }
+    for (int b = 0; b < batch_k; ++b) {
+      SEXP a = Rf_allocVector(VECSXP, 19);
+      SEXP parts[19] = {pos, (b & 1) ? R_NilValue : D, (b & 1) ? R_NilValue : T, deg, ei, ej, ed, et, iter, sk0, scool, scr,
+                        seps, Rf_ScalarInteger(window), Rf_ScalarInteger(freq), Rf_ScalarLogical(verbose), hi, hj, ht};
+      for (int q = 0; q < 19; ++q) SET_VECTOR_ELT(a, q, parts[q]);
+      SET_VECTOR_ELT(calls, b, a);
+    }
+    if (setjmp(error_jmp) != 0) {
+      printf("{\"error\": \"%s\", ", error_msg);
+      print_tail();
+      return 0;
+    }
+    SEXP out = fn(calls);
+    printf("{\"results\": [");
+    for (int b = 0; b < Rf_length(out); ++b) {
+      SEXP r = VECTOR_ELT(out, b);
+      printf("%s{\"positions\": ", b ? ", " : "");
+      print_vec(VECTOR_ELT(r, 0));
+      SEXP e = VECTOR_ELT(r, 6);
+      printf(", \"converged\": %d, \"iterations\": %d, \"final_mae\": %.17g, \"final_k\": %.17g, \"iterations_run\": %d, "
+             "\"error\": ", LOGICAL(VECTOR_ELT(r, 1))[0], INTEGER(VECTOR_ELT(r, 2))[0], REAL(VECTOR_ELT(r, 3))[0],
+             REAL(VECTOR_ELT(r, 4))[0], INTEGER(VECTOR_ELT(r, 5))[0]);
+      if (STRING_ELT(e, 0) == R_NaString) printf("null"); else print_json_string(CHAR(STRING_ELT(e, 0)));
+      printf(", \"holdout_sum_abs\": %.17g, \"holdout_count\": %.17g, \"n_names\": %d}", REAL(VECTOR_ELT(r, 7))[0],
+             REAL(VECTOR_ELT(r, 8))[0], Rf_length(Rf_getAttrib(r, R_NamesSymbol)));
+    }
+    printf("], ");
+    print_tail();
+    return 0;
+  }
+
+  call16 fn = (call16)find_routine("_topolow_optimize_layout_exact_cpp", 16);
+  if (!fn) {
     printf("{\"registration\": \"bad\"}\n");
     return 1;
   }
   if (setjmp(error_jmp) != 0) {
-    printf("{\"error\": \"%s\", \"protect_depth\": %d, \"interrupted\": %d}\n", error_msg, protect_depth, interrupted);
+    printf("{\"error\": \"%s\", \"interrupted\": %d, ", error_msg, interrupted);
+    print_tail();
     return 0;
   }
-  SEXP iter = Rf_ScalarInteger(n_iter);
-  SEXP sk0 = Rf_ScalarReal(k0), scool = Rf_ScalarReal(cool), scr = Rf_ScalarReal(c_rep), seps = Rf_ScalarReal(eps);
   SEXP out = fn(pos, D, T, deg, ei, ej, ed, et, iter, sk0, scool, scr, seps, Rf_ScalarInteger(window),
                 Rf_ScalarInteger(freq), Rf_ScalarLogical(verbose));
   printf("{\"names\": [");
   SEXP names = Rf_getAttrib(out, R_NamesSymbol);
   for (int i = 0; i < Rf_length(names); ++i) printf("%s\"%s\"", i ? ", " : "", CHAR(STRING_ELT(names, i)));
   SEXP p = VECTOR_ELT(out, 0);
-  printf("], \"dim\": [%d, %d], \"positions\": [", Rf_nrows(p), Rf_ncols(p));
-  for (R_xlen_t i = 0; i < XLENGTH(p); ++i) printf("%s%.17g", i ? ", " : "", REAL(p)[i]);
-  printf("], \"converged\": %d, \"iterations\": %d, \"final_mae\": %.17g, \"final_k\": %.17g, "
-         "\"types\": [%d, %d, %d, %d, %d], \"protect_depth\": %d, \"interrupt_polls\": %d}\n",
+  printf("], \"dim\": [%d, %d], \"positions\": ", Rf_nrows(p), Rf_ncols(p));
+  print_vec(p);
+  printf(", \"converged\": %d, \"iterations\": %d, \"final_mae\": %.17g, \"final_k\": %.17g, "
+         "\"types\": [%d, %d, %d, %d, %d], ",
          LOGICAL(VECTOR_ELT(out, 1))[0], INTEGER(VECTOR_ELT(out, 2))[0], REAL(VECTOR_ELT(out, 3))[0],
          REAL(VECTOR_ELT(out, 4))[0], VECTOR_ELT(out, 0)->type, VECTOR_ELT(out, 1)->type,
-         VECTOR_ELT(out, 2)->type, VECTOR_ELT(out, 3)->type, VECTOR_ELT(out, 4)->type, protect_depth,
-         interrupt_calls);
+         VECTOR_ELT(out, 2)->type, VECTOR_ELT(out, 3)->type, VECTOR_ELT(out, 4)->type);
+  print_tail();
   return 0;
 }

@@ -1,0 +1,117 @@
+"""Named problems of the statistical parity contract: the SAME definitions feed the oracle
+distributions committed under tests/golden/oracle_dist_*.json (tests/golden/make_oracle_distributions.py)
+and the GPU tests that compare the device schedules with them.  Test infrastructure."""
+import csv
+import functools
+import json
+import os
+
+import numpy as np
+
+from topolow_amd import antigenic, core, synthetic
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+H3N2 = dict(k0=14.76214, cooling_rate=0.03641074, c_repulsion=0.002943064)   # reference
+# inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:312-316
+
+
+def random_problem(n, dim, missing, seed, thresholds=0.0, n_iter=20, k0=3.0, cool=0.05, c_rep=0.02,
+                   check_freq=3, window=5, eps=1e-4):
+    """Synthetic mixture problem (topolow_amd.synthetic), optionally with a fraction of the measured
+    pairs turned into ">" / "<" thresholds that the true distance satisfies."""
+    prob = synthetic.make_problem(n, latent_dim=dim, missing=missing, seed=seed)
+    D = prob.dissimilarity
+    if thresholds > 0:
+        rng = np.random.default_rng(seed + 1)
+        M = D.astype(object)
+        iu, ju = np.triu_indices(n, 1)
+        for a, b in zip(iu, ju):
+            if not np.isnan(D[a, b]):
+                u = rng.random()
+                if u < thresholds / 2:
+                    M[a, b] = M[b, a] = ">" + repr(float(D[a, b]) * 0.9)
+                elif u < thresholds:
+                    M[a, b] = M[b, a] = "<" + repr(float(D[a, b]) * 1.1)
+            else:
+                M[a, b] = M[b, a] = None
+        for a in range(n):
+            M[a, a] = "0"
+        D = M
+    init = synthetic.initial_positions(prob.dissimilarity, dim, seed)
+    return core.prepare_layout_call(D, dim, n_iter, k0, cool, c_rep, eps, window, init, False, check_freq,
+                                    True), prob
+
+
+def cfg3_generator(n, censored=0.0, n_iter=1000, eps=1e-4, window=5, check_freq=3):
+    """BASELINE config 3's generator and parameters at `n` points; `censored`:
+    fraction of the measured pairs turned into ">" censoring at the 90th percentile (config 3b)."""
+    dim = 5
+    prob = synthetic.make_problem(n, latent_dim=dim, missing=0.7, seed=12345)
+    D = prob.dissimilarity
+    init = synthetic.initial_positions(D, dim, 12345)
+    m = D
+    if censored > 0:
+        iu, ju = np.triu_indices(n, 1)
+        vals = D[iu, ju]
+        rng = np.random.default_rng(1)
+        sel = ~np.isnan(vals) & (rng.random(iu.size) < censored)
+        q90 = np.nanquantile(vals, 0.9)
+        m = core.CodedMatrix(D.copy(), np.zeros((n, n), dtype=np.int32), None, True)
+        m.values[iu[sel], ju[sel]] = np.minimum(vals[sel], q90)
+        m.values[ju[sel], iu[sel]] = m.values[iu[sel], ju[sel]]
+        m.codes[iu[sel], ju[sel]] = 1
+        m.codes[ju[sel], iu[sel]] = 1
+    call = core.prepare_layout_call(m, dim, n_iter, 5.0, 0.01, 0.01, eps, window, init, False, check_freq, True)
+    return call, prob
+
+
+def h3n2_matrix():
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "h3n2_distances.csv"))))
+    return antigenic.titers_list_to_matrix(rows, "virusStrain", "virusYear", "serumStrain", "serumYear",
+                                           "distance", sort=True)
+
+
+def h3n2_call(ndim):
+    return core.prepare_layout_call(h3n2_matrix(), ndim, 1000, H3N2["k0"], H3N2["cooling_rate"],
+                                    H3N2["c_repulsion"], 1e-4, 5, None, False, 3, False, np.random.default_rng(7))
+
+
+def _syn1500():
+    call, prob = random_problem(1500, 5, 0.7, seed=777, n_iter=1000, k0=14.76, cool=0.0364, c_rep=0.00294)
+    return call, prob.dissimilarity
+
+
+def _cfg3gen(n, censored=0.0):
+    call, prob = cfg3_generator(n, censored)
+    return call, (prob.dissimilarity if censored == 0 else None)
+
+
+PROBLEMS = {
+    "syn1500_h3n2params": dict(fn=_syn1500, doc="random_problem(1500, 5, 0.7, seed=777, n_iter=1000, k0=14.76, "
+                               "cool=0.0364, c_rep=0.00294); eps 1e-4, window 5, check every 3"),
+    "cfg3gen_1500": dict(fn=functools.partial(_cfg3gen, 1500), doc="cfg3_generator(1500): config 3's generator "
+                         "(seed 12345, 70 % missing, ndim 5, k0 5, cooling 0.01, c_rep 0.01), default controller"),
+    "cfg3gen_2048": dict(fn=functools.partial(_cfg3gen, 2048), doc="cfg3_generator(2048)"),
+    "cfg3b_1500": dict(fn=functools.partial(_cfg3gen, 1500, 0.1), doc="cfg3_generator(1500, censored=0.1): 10 % "
+                       "of the measured pairs are '>' thresholds at the 90th percentile"),
+    "h3n2_ndim4": dict(fn=lambda: (h3n2_call(4), None), doc="Smith-2004 H3N2 panel (tests/golden/"
+                       "h3n2_distances.csv), ndim 4, published parameters, start positions default_rng(7)"),
+    "h3n2_ndim5": dict(fn=lambda: (h3n2_call(5), None), doc="the same, ndim 5 (BASELINE config 2)"),
+}
+
+
+@functools.lru_cache(maxsize=2)
+def build(name):
+    """(layout call, truth matrix or None) of a named problem."""
+    return PROBLEMS[name]["fn"]()
+
+
+def oracle_distribution(name):
+    with open(os.path.join(GOLD, f"oracle_dist_{name}.json")) as fh:
+        return json.load(fh)
+
+
+def cfg3_oracle_records():
+    import glob
+    return [json.load(open(f)) for f in sorted(glob.glob(os.path.join(GOLD, "cfg3_oracle_seed*.json")))
+            if "_n" not in os.path.basename(f)]

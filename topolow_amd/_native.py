@@ -35,12 +35,15 @@ class NativeError(RuntimeError):
 
 
 INTERRUPT_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+PRINT_CB = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
 
 
 class TopolowOptions(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("schedule", C.c_int32), ("precision", C.c_int32),
                 ("slab_stages", C.c_int32), ("device", C.c_int32), ("gs_max_n", C.c_int32),
-                ("reserved", C.c_int32 * 5), ("interrupt_cb", INTERRUPT_CB), ("interrupt_user", C.c_void_p)]
+                ("n_devices", C.c_int32), ("reserved", C.c_int32 * 4),
+                ("interrupt_cb", INTERRUPT_CB), ("interrupt_user", C.c_void_p),
+                ("print_cb", PRINT_CB), ("print_user", C.c_void_p), ("devices", C.POINTER(C.c_int32))]
 
 
 class TopolowRunStats(C.Structure):
@@ -135,6 +138,13 @@ def load() -> C.CDLL:
                                                         C.c_int32, C.c_int32, C.c_int32, dp, C.c_char_p,
                                                         C.c_size_t]
     lib.topolow_cv_fold.restype = C.c_int
+    i64p = C.POINTER(C.c_int64)
+    lib.topolow_cv_fold.argtypes = [C.POINTER(TopolowCellList), i64p, C.c_int64, C.c_int32, C.c_int32, ip, ip,
+                                    ip, ip, dp, ip, i64p, ip, ip, dp, i64p, dp]
+    lib.topolow_cell_list_index.restype = C.c_int
+    lib.topolow_cell_list_index.argtypes = [C.c_int32, C.c_int64, ip, ip, i64p, i64p, i64p]
+    lib.topolow_session_check_trace.restype = C.c_int
+    lib.topolow_session_check_trace.argtypes = [C.c_void_p, dp, C.c_int32, C.POINTER(C.c_int32)]
     lib.topolow_est_distances.restype = C.c_int
     lib.topolow_est_distances.argtypes = [dp, C.c_int32, C.c_int32, dp, C.c_int32, C.c_char_p,
                                           C.c_size_t]
@@ -257,6 +267,15 @@ def make_options(**kw) -> TopolowOptions:
     if cb is not None:   # Python callable() -> truthy to stop; keep a reference alive on the struct
         o._cb_keepalive = INTERRUPT_CB(lambda _user: 1 if cb() else 0)
         o.interrupt_cb = o._cb_keepalive
+    pr = cfg.get("print")
+    if pr is not None:   # Python callable(str): receives the verbose lines instead of stdout
+        o._pr_keepalive = PRINT_CB(lambda line, _user: pr(line.decode(errors="replace")))
+        o.print_cb = o._pr_keepalive
+    devs = cfg.get("devices")
+    if devs is not None:   # row-block sharded over these HIP ordinals (repeats allowed)
+        o._dev_keepalive = (C.c_int32 * len(devs))(*[int(d) for d in devs])
+        o.devices = C.cast(o._dev_keepalive, C.POINTER(C.c_int32))
+        o.n_devices = len(devs)
     return o
 
 
@@ -600,6 +619,15 @@ class Session:
         while self.enqueue(chunk) > 0:
             pass
         return self.sync()
+
+    def check_trace(self) -> np.ndarray:
+        """(iteration, MAE, k) of every convergence check of the current run, shape (checks, 3)."""
+        n = C.c_int32(0)
+        err = C.create_string_buffer(8)
+        _check(self.lib.topolow_session_check_trace(self._h, None, 0, C.byref(n)), err)
+        out = np.zeros((max(int(n.value), 1), 3), dtype=np.float64)
+        _check(self.lib.topolow_session_check_trace(self._h, _dp(out), int(n.value), C.byref(n)), err)
+        return out[: int(n.value)]
 
     def set_schedule(self, schedule: str):
         rc = self.lib.topolow_session_set_schedule(self._h, _SCHEDULES[schedule])

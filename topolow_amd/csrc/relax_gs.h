@@ -26,6 +26,7 @@
 #include <cstring>
 #include <numeric>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -85,7 +86,7 @@ struct GsOut {
   int iters_run;
   int n_checks;
   int nonfinite_iter;  // != 0: "Numerical instability at iteration %d"
-  int pad;
+  int aborted;         // != 0: the host raised the abort word (user interrupt)
   double hold_sum;               // sum |truth - distance| over the holdout pairs, final positions
   unsigned long long hold_cnt;
 };
@@ -109,6 +110,14 @@ struct GsDev {
   real* pos;             // n x dim row-major: in = initial positions, out = best positions
   real* best;            // n x dim scratch
   GsOut* out;
+  // host mailbox (pinned memory, device alias; nullable): ctrl[0] = abort word the host may raise at
+  // any time (read once per iteration: the interrupt poll of reference :364 reaches this one-launch
+  // kernel through it), ctrl[1] = iterations completed (written every 10th iteration);
+  // trace: (iteration, MAE, k) of every convergence check, up to trace_cap checks (verbose lines of
+  // reference :298-301)
+  int* ctrl;
+  double* trace;
+  int trace_cap, pad0;
   long long n_edges;
   double k0, cooling, c_rep, eps;
   uint64_t seed;
@@ -301,14 +310,19 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
   Controller ctl;
   ctl.init(P.k0, P.window, P.eps);
   double k = P.k0;
-  int converged = 0, iters_run = 0, n_checks = 0, nonfinite_iter = 0;
+  int converged = 0, iters_run = 0, n_checks = 0, nonfinite_iter = 0, aborted = 0;
   const int check_freq = P.check_freq < 1 ? 10 : P.check_freq;  // reference :181
   __syncthreads();
 
   for (int iter = 0; iter < P.n_iter; ++iter) {
+    if (P.ctrl != nullptr && tid == 0) {
+      sh_flag[1] = __hip_atomic_load(P.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (iter % 10 == 0) __hip_atomic_store(P.ctrl + 1, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // ---- this iteration's random permutation: rank of a hashed key (stable) ----
     for (int i = tid; i < n; i += nthr) keys[i] = gs_key(P.seed, iter, i);
     __syncthreads();
+    if (P.ctrl != nullptr && sh_flag[1] != 0) { aborted = 1; break; }   // block-uniform
     for (int i = tid; i < n; i += nthr) {
       const uint32_t ki = keys[i];
       int rank = 0;
@@ -456,6 +470,11 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
       gs_block_sum(s, c, sh_s, sh_c);
       const double err = c > 0 ? s / (double)c : 0.0;
       ++n_checks;
+      if (P.trace != nullptr && tid == 0 && n_checks <= P.trace_cap) {
+        P.trace[3 * (n_checks - 1) + 0] = (double)(iter + 1);
+        P.trace[3 * (n_checks - 1) + 1] = err;
+        P.trace[3 * (n_checks - 1) + 2] = k;
+      }
       const int action = ctl.observe(err, iter + 1, k);  // identical in every thread
       if (action & 2) {
         for (int q = tid; q < n * DIM; q += nthr) P.best[q] = pos[q];
@@ -503,7 +522,7 @@ __global__ __launch_bounds__(1024) void gs_embed_kernel(const GsDev<real>* __res
     o.iters_run = iters_run;
     o.n_checks = n_checks;
     o.nonfinite_iter = nonfinite_iter;
-    o.pad = 0;
+    o.aborted = aborted;
     *P.out = o;
   }
 }
@@ -530,6 +549,7 @@ struct GsResult {
   double* positions;  // n x dim col-major (caller-owned)
   int converged, iterations, iters_run, n_checks;
   int nonfinite_iter = 0;  // != 0: the non-finite guard fired at this iteration
+  int aborted = 0;
   double final_mae, final_k;
   double hold_sum = 0.0;
   long long hold_count = 0;
@@ -673,6 +693,8 @@ class GsArena {
 // several grids can be staged, run side by side on their own streams, and collected afterwards.
 struct GsBatchBase {
   virtual ~GsBatchBase() {}
+  // host mailbox shared by every problem of the grid (see GsDev::ctrl / trace); call before stage()
+  virtual void set_mailbox(int* ctrl_dev, double* trace_dev, int trace_cap) = 0;
   virtual void stage(const GsProblem* pbs, int count) = 0;   // validate, pack, upload
   virtual void launch(hipStream_t st) = 0;
   virtual int collect(GsResult* res, char* errbuf, size_t errlen) = 0;   // after the stream is idle
@@ -691,9 +713,13 @@ class GsBatch : public GsBatchBase {
   std::vector<Off> off;
   GsArena A;
   unsigned char* d_scratch = nullptr;   // best snapshots: device only
+  int* ctrl_dev = nullptr;
+  double* trace_dev = nullptr;
+  int trace_cap = 0;
 
  public:
   ~GsBatch() override { (void)hipFree(d_scratch); }
+  void set_mailbox(int* c, double* t, int cap) override { ctrl_dev = c; trace_dev = t; trace_cap = cap; }
 
   void stage(const GsProblem* pbs_, int count_) override {
     pbs = pbs_;
@@ -854,6 +880,9 @@ class GsBatch : public GsBatchBase {
         k.n_edges = p.n_edges;
         k.k0 = p.k0; k.cooling = p.cooling; k.c_rep = p.c_rep; k.eps = p.eps; k.seed = p.seed;
         k.n = p.n; k.n_iter = p.n_iter; k.check_freq = p.check_freq; k.window = p.window;
+        k.ctrl = ctrl_dev;
+        k.trace = b == 0 ? trace_dev : nullptr;   // the trace follows the grid's first problem
+        k.trace_cap = trace_cap;
       }
       GS_TRY(hipMemcpy(A.dev<GsDev<real>>(o_prob), h.data(), sizeof(GsDev<real>) * count, hipMemcpyHostToDevice));
     }
@@ -891,6 +920,7 @@ class GsBatch : public GsBatchBase {
       res[b].converged = o.converged; res[b].iterations = o.iterations; res[b].iters_run = o.iters_run;
       res[b].n_checks = o.n_checks; res[b].final_mae = o.final_mae; res[b].final_k = o.final_k;
       res[b].nonfinite_iter = o.nonfinite_iter;
+      res[b].aborted = o.aborted;
       res[b].hold_sum = o.hold_sum; res[b].hold_count = (long long)o.hold_cnt;
     }
     return rc;
@@ -902,30 +932,89 @@ inline GsBatchBase* gs_new_batch(int precision) {
   return new GsBatch<double>();
 }
 
+// Host mailbox of a one-launch GS grid: abort word + progress counter + check trace, in pinned memory.
+struct GsMailbox {
+  int* ctrl = nullptr;       // [0] abort, [1] iterations completed
+  double* trace = nullptr;   // 3 doubles per check
+  int* ctrl_dev = nullptr;
+  double* trace_dev = nullptr;
+  int trace_cap = 0;
+  void alloc(int cap) {
+    trace_cap = cap;
+    GS_TRY(hipHostMalloc((void**)&ctrl, 64, hipHostMallocMapped));
+    std::memset(ctrl, 0, 64);
+    GS_TRY(hipHostGetDevicePointer((void**)&ctrl_dev, ctrl, 0));
+    if (cap > 0) {
+      GS_TRY(hipHostMalloc((void**)&trace, sizeof(double) * 3 * (size_t)cap, hipHostMallocMapped));
+      std::memset(trace, 0, sizeof(double) * 3 * (size_t)cap);
+      GS_TRY(hipHostGetDevicePointer((void**)&trace_dev, trace, 0));
+    }
+  }
+  ~GsMailbox() {
+    if (ctrl) (void)hipHostFree(ctrl);
+    if (trace) (void)hipHostFree(trace);
+  }
+};
+
 // One grid, start to finish (the single-embedding path of topolow_optimize_layout_exact).
+//   interrupt_cb: polled while the launch runs, once per 50 iterations of progress (reference :364)
+//   and at least every 50 ms; a non-zero return raises the kernel's abort word.
+//   trace_out (3 doubles per check: iteration, MAE, k) / n_trace: the first problem's checks.
 inline int gs_run_batch(const GsProblem* pbs, GsResult* res, int count, int precision,
-                        double* device_seconds, char* errbuf, size_t errlen) {
+                        double* device_seconds, char* errbuf, size_t errlen,
+                        int32_t (*interrupt_cb)(void*) = nullptr, void* interrupt_user = nullptr,
+                        std::vector<double>* trace_out = nullptr) {
   int rc = TOPOLOW_OK;
   GsBatchBase* batch = gs_new_batch(precision);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  GsMailbox mb;   // outlives the launch on every path (the kernel reads and writes it)
   try {
+    if (interrupt_cb != nullptr || trace_out != nullptr) {
+      const int freq = pbs[0].check_freq < 1 ? 10 : pbs[0].check_freq;
+      mb.alloc(trace_out != nullptr ? pbs[0].n_iter / freq + 2 : 0);
+      batch->set_mailbox(mb.ctrl_dev, mb.trace_dev, mb.trace_cap);
+    }
     batch->stage(pbs, count);
-    hipEvent_t e0, e1;
     GS_TRY(hipEventCreate(&e0));
     GS_TRY(hipEventCreate(&e1));
     GS_TRY(hipEventRecord(e0, 0));
     batch->launch(0);
     GS_TRY(hipEventRecord(e1, 0));
+    if (interrupt_cb != nullptr) {
+      int polled_at = 0;
+      auto last_poll = std::chrono::steady_clock::now();
+      while (hipEventQuery(e1) == hipErrorNotReady) {
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+        const int progress = __atomic_load_n(mb.ctrl + 1, __ATOMIC_RELAXED);
+        const auto now = std::chrono::steady_clock::now();
+        if (progress - polled_at >= 50 || now - last_poll >= std::chrono::milliseconds(50)) {
+          polled_at = progress;
+          last_poll = now;
+          if (interrupt_cb(interrupt_user)) __atomic_store_n(mb.ctrl, 1, __ATOMIC_RELAXED);
+        }
+      }
+    }
     GS_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
     GS_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (device_seconds) *device_seconds = ms * 1e-3;
     rc = batch->collect(res, errbuf, errlen);
+    if (trace_out != nullptr) {
+      const int nc = std::min(res[0].n_checks, mb.trace_cap);
+      trace_out->assign(mb.trace, mb.trace + 3 * (size_t)nc);
+    }
+    for (int b = 0; b < count && rc == TOPOLOW_OK; ++b)
+      if (res[b].aborted) {
+        if (errbuf && errlen) snprintf(errbuf, errlen, "interrupted by the caller");
+        rc = TOPOLOW_ERR_INTERRUPTED;
+      }
   } catch (const GsHipError& e) {
     if (errbuf && errlen) snprintf(errbuf, errlen, "%s", e.msg.c_str());
     rc = e.code;
+    (void)hipStreamSynchronize(0);
   }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) { (void)hipEventSynchronize(e1); (void)hipEventDestroy(e1); }
   delete batch;
   return rc;
 }

@@ -793,7 +793,8 @@ template <typename real>
 __global__ __launch_bounds__(kCtlThreads) void controller_kernel(
     RunState* st, RunState* mailbox, const double* __restrict__ part_sum,
     const unsigned long long* __restrict__ part_cnt, int n_parts, const real* __restrict__ pos,
-    real* __restrict__ best_pos, long long n_values, int iter1, double k_after) {
+    real* __restrict__ best_pos, long long n_values, int iter1, double k_after,
+    double* __restrict__ trace, int trace_cap) {
   if (st->stopped) return;
   __shared__ double sh_s[kCtlThreads];
   __shared__ unsigned long long sh_c[kCtlThreads];
@@ -815,6 +816,11 @@ __global__ __launch_bounds__(kCtlThreads) void controller_kernel(
     const double err = sh_c[0] > 0 ? sh_s[0] / (double)sh_c[0] : 0.0;  // reference :296
     const int action = st->ctl.observe(err, iter1, k_after);
     st->last_mae = err;
+    if (trace != nullptr && st->n_checks < trace_cap) {   // (iteration, MAE, k) of every check
+      trace[3 * st->n_checks + 0] = (double)iter1;
+      trace[3 * st->n_checks + 1] = err;
+      trace[3 * st->n_checks + 2] = k_after;
+    }
     st->n_checks += 1;
     st->iter_base = iter1;
     st->k_base = k_after;

@@ -47,6 +47,40 @@ void set_err(char* errbuf, size_t errlen, const char* fmt, ...) {
   va_end(ap);
 }
 
+// verbose lines go to the caller's sink (topolow_options.print_cb) or stdout
+void emit(const topolow_options& opt, const char* fmt, ...) {
+  char line[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(line, sizeof line, fmt, ap);
+  va_end(ap);
+  if (opt.print_cb) opt.print_cb(line, opt.print_user);
+  else { std::fputs(line, stdout); std::fflush(stdout); }
+}
+
+// The reference's opening lines (src/optimization.cpp:183-188) plus which device path runs.
+void emit_header(const topolow_options& opt, const char* path, int n, double k0, double cooling, double c_rep) {
+  emit(opt, "=== Exact Algorithm (O(N^2) Full Pairwise) on HIP: %s ===\n", path);
+  emit(opt, "Points: %d, Pairs per iteration: %lld\n", n, (long long)n * (n - 1) / 2);
+  emit(opt, "Parameters: k0=%g, cooling=%g, c_rep=%g\n", k0, cooling, c_rep);
+}
+
+// Progress lines of the checks [from, to) of a trace (3 doubles per check), with the reference's
+// cadence: checks that fall on a multiple of 10 iterations or on the last one (:298-301).
+void emit_checks(const topolow_options& opt, const double* trace, int from, int to, int n_iter) {
+  for (int c = from; c < to; ++c) {
+    const int it = (int)trace[3 * c];
+    if (it % 10 == 0 || it == n_iter)
+      emit(opt, "Iter %d/%d, MAE=%g, k=%g\n", it, n_iter, trace[3 * c + 1], trace[3 * c + 2]);
+  }
+}
+
+// Closing line of a converged run (:334-336, :351-353): the controller's counters tell which rule fired.
+void emit_converged(const topolow_options& opt, bool plateau, int best_iter, double best_mae) {
+  if (plateau) emit(opt, "Converged (plateau) at iter %d, MAE=%g\n", best_iter, best_mae);
+  else emit(opt, "Converged (MAE worsening, best restored) at iter %d, MAE=%g\n", best_iter, best_mae);
+}
+
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \
     hipError_t e_ = (expr);                                                             \
@@ -137,6 +171,9 @@ struct topolow_session {
   DevBuf<RunState> state;
   RunState* mailbox = nullptr;      // pinned host memory
   RunState* mailbox_dev = nullptr;  // device alias of mailbox
+  double* trace = nullptr;          // pinned: (iteration, MAE, k) of every check of the current run
+  double* trace_dev = nullptr;
+  int trace_cap = 0;
 
   // run parameters
   int n_iter = 0, check_freq = 3, window = 5, fixed_stages = 0;
@@ -165,6 +202,7 @@ struct topolow_session {
     for (hipEvent_t e : pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (mailbox) (void)hipHostFree(mailbox);
+    if (trace) (void)hipHostFree(trace);
     if (ev_iter_done) (void)hipEventDestroy(ev_iter_done);
     if (ev_check_done) (void)hipEventDestroy(ev_check_done);
     if (check_stream) (void)hipStreamDestroy(check_stream);
@@ -355,11 +393,11 @@ void launch_controller(topolow_session* s, const void* pos, int iter1, double k_
   if (s->precision == TOPOLOW_PRECISION_F64) {
     hipLaunchKernelGGL((controller_kernel<double>), dim3(1), dim3(kCtlThreads), 0, s->stream,
                        s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, error_parts(s),
-                       (const double*)pos, (double*)s->best.p, nv, iter1, k_after);
+                       (const double*)pos, (double*)s->best.p, nv, iter1, k_after, s->trace_dev, s->trace_cap);
   } else {
     hipLaunchKernelGGL((controller_kernel<float>), dim3(1), dim3(kCtlThreads), 0, s->stream,
                        s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, error_parts(s),
-                       (const float*)pos, (float*)s->best.p, nv, iter1, k_after);
+                       (const float*)pos, (float*)s->best.p, nv, iter1, k_after, s->trace_dev, s->trace_cap);
   }
   HIP_TRY(hipGetLastError());
 }
@@ -836,6 +874,15 @@ int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double 
     s->eps = relative_epsilon;
     s->window = convergence_window;
     s->check_freq = convergence_check_freq < 1 ? 10 : convergence_check_freq;  // reference :181
+    {
+      const int need = n_iter / s->check_freq + 2;
+      if (need > s->trace_cap) {
+        if (s->trace) { (void)hipHostFree(s->trace); s->trace = nullptr; s->trace_cap = 0; }
+        HIP_TRY(hipHostMalloc((void**)&s->trace, sizeof(double) * 3 * (size_t)need, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&s->trace_dev, s->trace, 0));
+        s->trace_cap = need;
+      }
+    }
     s->seed = seed;
     s->fixed_stages = slab_stages;
     s->iters_enqueued = 0;
@@ -872,7 +919,12 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
       if (s->schedule == TOPOLOW_SCHEDULE_GS) {
         TL_DISPATCH_DIM(s->dim, launch_tilegs_iteration, s, s->pos[s->cur].p, iter, s->k_host);
       } else {
-        const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_for_k(s->k_host);
+        int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_for_k(s->k_host);
+        {   // EXPERIMENT: TOPOLOW_SLAB_EARLY="<iterations>:<stages>" -- more stages while the layout unfolds
+          static const int early_iters = [] { const char* e = getenv("TOPOLOW_SLAB_EARLY"); return e ? atoi(e) : 0; }();
+          static const int early_stages = [] { const char* e = getenv("TOPOLOW_SLAB_EARLY"); const char* c = e ? strchr(e, ':') : nullptr; return c ? atoi(c + 1) : 0; }();
+          if (iter < early_iters && early_stages > stages) stages = early_stages;
+        }
         const SlabGeom g = slab_geom(s->n, stages);
         for (int slot = 0; slot < g.n_stages; ++slot) {
           const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
@@ -973,6 +1025,18 @@ int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* c
     if (final_k) *final_k = st.ctl.best_k;
   });
   return rc != TOPOLOW_OK ? rc : rc_nonfinite;
+}
+
+int topolow_session_check_trace(topolow_session* s, double* out, int32_t max_checks, int32_t* n_checks) {
+  if (!s || (!out && max_checks > 0) || !n_checks) return TOPOLOW_ERR_BAD_ARGUMENT;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  (void)hipStreamSynchronize(s->check_stream);
+  const int have = std::min(s->mailbox ? s->mailbox->n_checks : 0, s->trace_cap);
+  *n_checks = have;
+  const int take = std::min(have, (int)max_checks);
+  if (take > 0) std::memcpy(out, s->trace, sizeof(double) * 3 * (size_t)take);
+  return TOPOLOW_OK;
 }
 
 int topolow_session_set_profiling(topolow_session* s, int32_t enable) {
@@ -1184,6 +1248,28 @@ int topolow_optimize_layout_exact_batch(const topolow_problem* problems, topolow
 }
 
 // ---- post metric -----------------------------------------------------------------------
+int topolow_cell_list_index(int32_t n, int64_t n_cells, const int32_t* row, const int32_t* col,
+                            int64_t* pos_of, int64_t* by_row, int64_t* row_ptr) {
+  if (n < 1 || n_cells < 0 || !pos_of || !by_row || !row_ptr || (n_cells > 0 && (!row || !col)))
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  for (int64_t q = 0; q < (int64_t)n * n; ++q) pos_of[q] = -1;
+  for (int i = 0; i <= n; ++i) row_ptr[i] = 0;
+  for (int64_t c = 0; c < n_cells; ++c) {
+    if (row[c] < 0 || row[c] >= n || col[c] < 0 || col[c] >= n) return TOPOLOW_ERR_BAD_ARGUMENT;
+    pos_of[(int64_t)row[c] + (int64_t)col[c] * n] = c;   // linear column-major index, as R's which()
+    row_ptr[row[c] + 1] += 1;
+  }
+  for (int i = 0; i < n; ++i) row_ptr[i + 1] += row_ptr[i];
+  try {
+    // counting sort by row; the listing is column-major, so columns ascend inside every row
+    std::vector<int64_t> at(row_ptr, row_ptr + n);
+    for (int64_t c = 0; c < n_cells; ++c) by_row[at[row[c]]++] = c;
+  } catch (const std::bad_alloc&) {
+    return TOPOLOW_ERR_HIP;
+  }
+  return TOPOLOW_OK;
+}
+
 int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_t n_picks,
                     int32_t preserve_order, int32_t named, int32_t* order, int32_t* degrees,
                     int32_t* edge_i, int32_t* edge_j, double* edge_dist, int32_t* edge_thresh,
@@ -1267,9 +1353,12 @@ int topolow_optimize_layout_exact(
     res.positions = positions_out;
     int rc_inner = TOPOLOW_OK;
     double dev_s = 0.0;
+    std::vector<double> trace;
+    if (verbose) emit_header(opt, "one-workgroup Gauss-Seidel", n, k0, cooling_rate, c_repulsion);
     const int rc = guarded(errbuf, errlen, [&] {
       select_device(opt.device);
-      rc_inner = gs_run_batch(&pb, &res, 1, precision, &dev_s, errbuf, errlen);
+      rc_inner = gs_run_batch(&pb, &res, 1, precision, &dev_s, errbuf, errlen, opt.interrupt_cb,
+                              opt.interrupt_user, verbose ? &trace : nullptr);
     });
     if (rc != TOPOLOW_OK) return rc;
     if (rc_inner != TOPOLOW_OK) return rc_inner;
@@ -1284,8 +1373,16 @@ int topolow_optimize_layout_exact(
       stats->device_seconds = dev_s;
       stats->total_seconds = now_s() - t_start;
     }
-    if (verbose) std::printf("topolow_relax[gs]: n=%d iters_run=%d best_iter=%d mae=%g\n", n,
-                             res.iters_run, res.iterations, res.final_mae);
+    if (verbose) {
+      const int nc = (int)(trace.size() / 3);
+      emit_checks(opt, trace.data(), 0, nc, n_iter);
+      if (res.converged) {
+        // the rule that stopped the run: the last `window` checks all lie inside the plateau band
+        // (plateau) or above it (worsening); the last check decides
+        const bool plateau = nc > 0 && trace[3 * (nc - 1) + 1] <= res.final_mae * (1.0 + relative_epsilon);
+        emit_converged(opt, plateau, res.iterations, res.final_mae);
+      }
+    }
     return TOPOLOW_OK;
   }
 
@@ -1314,13 +1411,18 @@ int topolow_optimize_layout_exact(
                                opt.slab_stages, errbuf, errlen);
     if (rc) break;
     t_dev0 = now_s();
-    if (verbose) {
-      std::printf("=== %s schedule on HIP device %d ===\n", tile_gs ? "Exact tile Gauss-Seidel" : "Slab",
-                  s->device);
-      std::printf("Points: %d, Pairs per iteration: %lld\n", n, (long long)n * (n - 1) / 2);
-      std::printf("Parameters: k0=%g, cooling=%g, c_rep=%g\n", k0, cooling_rate, c_repulsion);
-    }
-    int last_reported = 0;
+    if (verbose)
+      emit_header(opt, tile_gs ? "tile Gauss-Seidel" : "row-owner slabs", n, k0, cooling_rate, c_repulsion);
+    int reported = 0;
+    std::vector<double> trace;
+    auto report = [&] {   // verbose: the checks since the last report (waits for the enqueued work)
+      int nc = 0;
+      if (topolow_session_check_trace(s, nullptr, 0, &nc) != TOPOLOW_OK || nc <= reported) return;
+      trace.resize(3 * (size_t)nc);
+      if (topolow_session_check_trace(s, trace.data(), nc, &nc) != TOPOLOW_OK) return;
+      emit_checks(opt, trace.data(), reported, nc, n_iter);
+      reported = nc;
+    };
     for (;;) {
       int enq = 0;
       // 50 iterations at a time: the reference's interrupt cadence (src/optimization.cpp:364)
@@ -1331,15 +1433,9 @@ int topolow_optimize_layout_exact(
         rc = TOPOLOW_ERR_INTERRUPTED;
         break;
       }
-      if (verbose) {  // progress like the reference's Rcout lines (:298-301), one per 50 iterations
-        int it = 0, stp = 0;
-        double mae = 0.0;
-        if (topolow_session_sync(s, &it, &stp, &mae, nullptr, 0) == TOPOLOW_OK && it != last_reported) {
-          std::printf("Iter %d/%d, MAE=%g\n", it, n_iter, mae);
-          last_reported = it;
-        }
-      }
+      if (verbose) report();
     }
+    if (rc == TOPOLOW_OK && verbose) report();
     if (rc) break;
     double last = 0.0;
     rc = topolow_session_sync(s, &iters_run, &stopped, &last, errbuf, errlen);
@@ -1357,9 +1453,8 @@ int topolow_optimize_layout_exact(
     stats->device_seconds = t_dev1 - t_dev0;
     stats->stage_launches = s->stage_launches;
   }
-  if (rc == TOPOLOW_OK && verbose)
-    std::printf("topolow_relax[slab]: n=%d iters_run=%d best_iter=%d mae=%g\n", n, iters_run,
-                *iterations, *final_mae);
+  if (rc == TOPOLOW_OK && verbose && *converged)
+    emit_converged(opt, s->mailbox->ctl.plateau >= s->mailbox->ctl.window, *iterations, *final_mae);
   topolow_session_destroy(s);
   if (rc == TOPOLOW_OK && stats) stats->total_seconds = now_s() - t_start;
   return rc;
