@@ -46,12 +46,15 @@ typedef struct topolow_options {
                            std::random_device, src/optimization.cpp:153-154) */
   int32_t schedule;     /* TOPOLOW_SCHEDULE_* */
   int32_t precision;    /* TOPOLOW_PRECISION_* */
-  int32_t slab_stages;  /* 0 = adaptive: max(4, pow2ceil(k/2.5)) per check interval */
+  int32_t slab_stages;  /* 0 = adaptive: topolow_slab_stages_at(iteration, k) */
   int32_t device;       /* HIP device ordinal; -1 = current device */
   int32_t gs_max_n;     /* AUTO switches to the slab schedule above this n; 0 = default */
   int32_t n_devices;    /* > 1 (or a non-NULL `devices`): ONE embedding row-block sharded over
                            devices[0..n_devices) -- see topolow_optimize_layout_exact_sharded */
-  int32_t reserved[4];
+  int32_t keep_labels;  /* 0 (default): the multi-workgroup schedules relabel the points at random (seeded
+                           by `seed`), so that a slab / a tile is a random subset of the points rather
+                           than a run of consecutive ones; non-zero: keep the caller's order */
+  int32_t reserved[3];
   /* Polled every 50 iterations like Rcpp::checkUserInterrupt() in the reference
    * (src/optimization.cpp:364); a non-zero return abandons the run with TOPOLOW_ERR_INTERRUPTED
    * after device memory has been released.  NULL = never. */
@@ -76,7 +79,8 @@ typedef struct topolow_run_stats {
   double  device_seconds;   /* relaxation loop only, device resident */
   double  total_seconds;    /* including upload/encode/download */
   int64_t stage_launches;
-  int64_t reserved[4];
+  double  setup_seconds;    /* session creation, verification of the inputs, upload, encode */
+  int64_t reserved[3];
 } topolow_run_stats;
 
 void topolow_default_options(topolow_options* opt);
@@ -203,6 +207,17 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
                            size_t errlen);
 void topolow_session_destroy(topolow_session* s);
 
+/* Optional, before anything is loaded: store the points in a random order (a permutation drawn from
+ * `seed`; 0 = the caller's order).  A slab -- a run of consecutive session labels -- is then a random
+ * subset of the caller's points, not a run of points that lie next to each other on the reference's
+ * random-walk start (R/core.R:407-415).  Every entry point that takes or returns HOST arrays keeps
+ * speaking the caller's labels; device buffers handed to topolow_session_stage / _edge_error /
+ * _check_partial are in session labels (topolow_session_labels gives the map).  Sessions that share
+ * n and seed share the permutation (row-sharded runs). */
+int topolow_session_set_relabel(topolow_session* s, uint64_t seed, char* errbuf, size_t errlen);
+/* session label q holds the caller's point session_to_caller[q] (n entries). */
+int topolow_session_labels(const topolow_session* s, int32_t* session_to_caller);
+
 /* Encode the reference's dense inputs (host pointers, R layout) into the session's HBM
  * block.  Only rows [row_begin,row_end) are read. */
 int topolow_session_load_dense(topolow_session* s, const double* dissimilarity_matrix,
@@ -293,9 +308,75 @@ int32_t topolow_session_position_rows(const topolow_session* s);
 int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_out,
                           int32_t iter, int32_t stage, int32_t n_stages, double k,
                           char* errbuf, size_t errlen);
+/* The multi-process form of the convergence check (one process per GPU, the caller owns the
+ * collectives): check_partial reduces this block's share of the measured pairs on d_pos into two
+ * doubles (sum, count) at the DEVICE address d_out2; the caller all-reduces them (RCCL) and hands the
+ * totals to controller_step, which runs the reference's controller (src/optimization.cpp:303-357) on
+ * the device -- snapshot, counters, stop flag -- exactly as the session's own loop does.  Nothing
+ * here waits for the device.  Valid between topolow_session_begin and topolow_session_finish. */
+int topolow_session_check_partial(topolow_session* s, const void* d_pos, double* d_out2, char* errbuf,
+                                  size_t errlen);
+int topolow_session_controller_step(topolow_session* s, const double* d_total2, const void* d_pos,
+                                    int32_t iter1, double k_after, char* errbuf, size_t errlen);
+/* First iteration (1-based) at which one of this block's rows became non-finite, 0 = none. Waits. */
+int topolow_session_first_nonfinite(topolow_session* s, int32_t* iteration);
 /* Partial edge error of this session's edge list on d_pos: (sum, count). Synchronous. */
 int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* sum,
                                int64_t* count, char* errbuf, size_t errlen);
+
+/* ---------------------------------------------------------------------------------------
+ * ONE embedding row-sharded over several GPUs from ONE process (BASELINE config 4: the R host is a
+ * single process, reference src/RcppExports.cpp:16-39).  Block b owns a contiguous row block of the
+ * encoded matrix and moves its own points; a stage kernel stores its updated rows straight into the
+ * position buffers of all blocks (peer stores over xGMI), blocks meet at HIP-event barriers, and the
+ * convergence controller is replicated from per-block (sum, count) partials -- no host round trip
+ * per stage or per check (csrc/relax_sharded_engine.h).  Results equal the one-session run of the
+ * same seed: positions bit for bit, the MAE to rounding (its partial sums are grouped by block).
+ * ------------------------------------------------------------------------------------- */
+typedef struct topolow_shard_stats {
+  int32_t blocks, iterations_run, n_checks, reserved0;
+  double loop_seconds;           /* host wall time of the relaxation loop, all blocks */
+  double total_seconds;          /* including session creation, upload, encode, download */
+  double stage_kernel_seconds;   /* block 0: summed durations of its stage kernels (HIP events) */
+  double check_kernel_seconds;   /* block 0: error pass + partial exchange + controller */
+  int64_t stage_launches;        /* block 0 */
+  int64_t exchanges;             /* cross-block barriers */
+  int64_t reserved[4];
+} topolow_shard_stats;
+
+/* Row block `block` of `blocks` over n rows: contiguous, whole 8-row workgroups; returns how many
+ * blocks hold at least one row (<= blocks; trailing blocks of a small problem are empty and
+ * dropped).  block < 0: only the count. */
+int32_t topolow_shard_rows(int32_t n, int32_t blocks, int32_t block, int32_t* row_begin, int32_t* row_end);
+
+/* The `.Call` payload row-sharded over opt->devices[0 .. n_devices) (an ordinal may repeat: several
+ * row blocks on one GPU).  Arguments and outputs as topolow_optimize_layout_exact;
+ * dissimilarity_matrix and threshold_matrix may both be NULL: the edge list then IS the matrix (large
+ * problems never build the dense n x n host matrices).  Slab schedule only. */
+int topolow_optimize_layout_exact_sharded(
+    const double* initial_positions, int32_t n, int32_t ndim,
+    const double* dissimilarity_matrix, const int32_t* threshold_matrix,
+    const int32_t* degrees,
+    const int32_t* edge_i, const int32_t* edge_j, const double* edge_dist,
+    const int32_t* edge_thresh, int64_t n_edges,
+    int32_t n_iter, double k0, double cooling_rate, double c_repulsion,
+    double relative_epsilon, int32_t convergence_window, int32_t convergence_check_freq,
+    int32_t verbose, const topolow_options* opt,
+    double* positions_out, int32_t* converged, int32_t* iterations, double* final_mae,
+    double* final_k, topolow_shard_stats* stats, char* errbuf, size_t errlen);
+
+/* The same run over sessions the caller has created and loaded itself (targets, degrees and each
+ * block's share of the MAE edges -- pair {lo, hi} belongs to the block that owns lo when lo + hi is
+ * even and hi when it is odd): row blocks that tile [0, n) in order, slab schedule, one precision.
+ * profile != 0: block 0's kernels are bracketed by timing events (fills the *_kernel_seconds). */
+int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, const double* initial_positions,
+                                 int32_t n_iter, double k0, double cooling_rate, double c_repulsion,
+                                 double relative_epsilon, int32_t convergence_window,
+                                 int32_t convergence_check_freq, uint64_t seed, int32_t slab_stages,
+                                 int32_t (*interrupt_cb)(void* user), void* interrupt_user, int32_t profile,
+                                 double* positions_out, int32_t* converged, int32_t* iterations,
+                                 double* final_mae, double* final_k, topolow_shard_stats* stats,
+                                 char* errbuf, size_t errlen);
 
 /* ---------------------------------------------------------------------------------------
  * Host-side helpers exported for tests and integrators (no GPU needed).
@@ -304,8 +385,11 @@ int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* su
  * r1_end; second range empty unless the slab wraps) in execution order; returns n_stages. */
 int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t iter,
                           int32_t* ranges_out, int32_t max_stages);
-/* Stage count the adaptive policy picks for spring constant k. */
+/* Stage count the adaptive policy picks for spring constant k: max(4, pow2ceil(k / 2.5)). */
 int32_t topolow_slab_stages_for_k(double k);
+/* Stage count of iteration `iter` (0-based) at spring constant k when slab_stages = 0: the policy above,
+ * and at least 16 stages during the first 16 iterations, while the layout unfolds from its start. */
+int32_t topolow_slab_stages_at(int32_t iter, double k);
 /* Visiting order of the GS tournament schedule for iteration `iter`: n(n-1)/2 pairs
  * (a,b) as 2 int32 each, in an order equivalent to what the kernel executes. */
 int64_t topolow_gs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_t* pairs_out);

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:   # a process that uses both torch and libtopolow_relax.so must load torch's HIP runtime FIRST (torch
+    import torch  # noqa: F401  ships its own copy; loaded second it reports "No HIP GPUs are available")
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

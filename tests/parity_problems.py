@@ -81,8 +81,8 @@ def _syn1500():
     return call, prob.dissimilarity
 
 
-def _cfg3gen(n, censored=0.0):
-    call, prob = cfg3_generator(n, censored)
+def _cfg3gen(n, censored=0.0, eps=1e-4):
+    call, prob = cfg3_generator(n, censored, eps=eps)
     return call, (prob.dissimilarity if censored == 0 else None)
 
 
@@ -94,6 +94,12 @@ PROBLEMS = {
     "cfg3gen_2048": dict(fn=functools.partial(_cfg3gen, 2048), doc="cfg3_generator(2048)"),
     "cfg3b_1500": dict(fn=functools.partial(_cfg3gen, 1500, 0.1), doc="cfg3_generator(1500, censored=0.1): 10 % "
                        "of the measured pairs are '>' thresholds at the 90th percentile"),
+    # the relative_epsilon values the reference's own callers pass: Euclidify's final embedding 1e-6
+    # (R/core.R:1263), the notebooks 1e-10 (inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:905)
+    "cfg3gen_1500_eps1e-6": dict(fn=functools.partial(_cfg3gen, 1500, 0.0, 1e-6),
+                                 doc="cfg3_generator(1500, eps=1e-6)"),
+    "cfg3gen_1500_eps1e-10": dict(fn=functools.partial(_cfg3gen, 1500, 0.0, 1e-10),
+                                  doc="cfg3_generator(1500, eps=1e-10)"),
     "h3n2_ndim4": dict(fn=lambda: (h3n2_call(4), None), doc="Smith-2004 H3N2 panel (tests/golden/"
                        "h3n2_distances.csv), ndim 4, published parameters, start positions default_rng(7)"),
     "h3n2_ndim5": dict(fn=lambda: (h3n2_call(5), None), doc="the same, ndim 5 (BASELINE config 2)"),

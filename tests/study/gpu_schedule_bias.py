@@ -26,7 +26,7 @@ def main():
     else:
         call, _ = pp.build(name)
     n, dim = call.initial_positions.shape
-    res = {"problem": name, "n": n, "damp": os.environ.get("TOPOLOW_SLAB_DAMP", "0"), "variants": {}}
+    res = {"problem": name, "n": n, "damp": os.environ.get("TOPOLOW_SLAB_EARLY", "-"), "variants": {}}
     for v in variants:
         kind, _, arg = v.partition(":")
         rows = []
@@ -61,7 +61,12 @@ def main():
         res["variants"][v] = dict(mean=float(fm.mean()), sd=float(fm.std(ddof=1)) if len(fm) > 1 else 0.0,
                                   iters=float(np.mean([r["iterations"] for r in rows])), seconds=time.time() - t0,
                                   runs=rows)
-        print(name, "damp", res["damp"], v, "mean %.5f sd %.5f iters %.0f (%.0f s)" %
+        if kind == "trace":
+            for r in rows:
+                t = r["trace"]
+                print("   seed", r["seed"], "MAE@6,9,12,33,63:", " ".join("%.4f" % t[q] for q in (1, 2, 3, 10, 20) if q < len(t)),
+                      "final %.5f" % r["final_mae"], flush=True)
+        print(name, "early", os.environ.get("TOPOLOW_SLAB_EARLY", "-"), v, "mean %.5f sd %.5f iters %.0f (%.0f s)" %
               (fm.mean(), res["variants"][v]["sd"], res["variants"][v]["iters"], time.time() - t0), flush=True)
     json.dump(res, open(out_path, "w"))
 

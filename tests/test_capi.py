@@ -69,6 +69,9 @@ def test_slab_plan_covers_every_column_once(n, stages):
 def test_slab_stage_policy():
     assert _native.slab_stages_for_k(0.1) == 4 and _native.slab_stages_for_k(10.0) == 4
     assert _native.slab_stages_for_k(14.76) == 8 and _native.slab_stages_for_k(30.0) == 16
+    # while the layout unfolds (first 16 iterations) never fewer than 16 stages
+    assert _native.slab_stages_at(0, 5.0) == 16 and _native.slab_stages_at(15, 5.0) == 16
+    assert _native.slab_stages_at(16, 5.0) == 4 and _native.slab_stages_at(3, 100.0) == 64
 
 
 @pytest.mark.parametrize("n", [2, 3, 5, 8, 33, 64, 101])

@@ -1,0 +1,122 @@
+"""The native row-sharded path (BASELINE config 4: ONE embedding over several GPUs from ONE process,
+include/topolow_relax.h: topolow_optimize_layout_exact_sharded / topolow_sessions_run_sharded) on the one
+GPU a test box has: several row blocks on the same device exchange their position slices exactly as
+blocks on different GPUs would (peer stores from the stage kernel's epilogue, HIP-event barriers, replicated
+controller) -- only the wire differs.  Run with -m gpu.
+
+The slab stage moves every row independently of how rows are grouped into blocks, and the controller is
+replicated, so a sharded run must reproduce the one-session run of the same seed: positions bit for bit,
+the MAE to the rounding of its partial sums (they are grouped by block)."""
+import numpy as np
+import pytest
+
+from oracle import topolow_oracle as orc
+from tests import parity_problems as pp
+from tests.conftest import layout_call_args
+from topolow_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert np.array_equal(a.positions, b.positions)
+    assert (a.converged, a.iterations, a.final_k) == (b.converged, b.iterations, b.final_k)
+    assert a.final_mae == pytest.approx(b.final_mae, rel=1e-6)
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.15])
+def test_row_blocks_on_one_device_equal_the_single_session(thr):
+    call, _ = pp.random_problem(1203, 5, 0.7, seed=31, thresholds=thr, n_iter=400, k0=8.0, cool=0.03, c_rep=0.01)
+    one = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=5, schedule="slab")
+    assert one.converged and one.info["schedule"] == "slab"
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 8):
+        got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=5, devices=devs)
+        _same(got, one)
+        assert got.info["iterations_run"] == one.info["iterations_run"]
+    # the edge list as the matrix (no dense n x n host arrays), through the sharded entry itself
+    coo = _native.optimize_layout_exact_sharded(
+        call.initial_positions, call.degrees, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.n_iter,
+        call.k0, call.cooling_rate, call.c_repulsion, call.relative_epsilon, call.convergence_window,
+        call.convergence_check_freq, devices=[0, 0, 0, 0], seed=5)
+    _same(coo, one)
+    assert coo.info["blocks"] == 4 and coo.info["exchanges"] > coo.info["iterations_run"]
+    sm, cnt = orc.edge_error(coo.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert coo.final_mae == pytest.approx(sm / cnt, rel=2e-5)
+
+
+def test_sharded_small_problem_drops_empty_blocks_and_runs_exhausted():
+    """n = 20 over 8 requested blocks: 8-row blocks, 3 of them hold rows (an empty block is dropped, it never
+    becomes a session); a run that exhausts its iterations restores the best snapshot like the one-session run."""
+    assert _native.shard_rows(20, 8) == [(0, 8), (8, 16), (16, 20)]
+    call, _ = pp.random_problem(20, 2, 0.2, seed=3, n_iter=7, check_freq=2)
+    one = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=9, schedule="slab")
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=9, devices=[0] * 8)
+    _same(got, one)
+    assert not got.converged
+
+
+def test_sharded_guards_interrupt_and_verbose():
+    call, _ = pp.random_problem(900, 3, 0.5, seed=8, n_iter=200)
+    bad = call.initial_positions.copy()
+    bad[17, 1] = np.inf
+    args = list(layout_call_args(call)); args[0] = bad
+    with pytest.raises(_native.NativeError, match=r"Numerical instability at iteration 10\. Reduce k0 or c_repulsion\.") as ei:
+        _native.optimize_layout_exact_arrays(*args, seed=1, devices=[0, 0])
+    assert ei.value.code == _native.ERR_NONFINITE
+    with pytest.raises(_native.NativeError) as ei:
+        _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1, devices=[0, 0], schedule="gs")
+    assert ei.value.code == _native.ERR_UNSUPPORTED
+    polls = []
+
+    def stop_at_second_poll():
+        polls.append(1)
+        return len(polls) >= 2
+    import dataclasses
+    long_call = dataclasses.replace(call, n_iter=400, relative_epsilon=1e-12, convergence_window=10 ** 6)
+    with pytest.raises(_native.NativeError) as ei:
+        _native.optimize_layout_exact_arrays(*layout_call_args(long_call), seed=1, devices=[0, 0, 0],
+                                             interrupt=stop_at_second_poll)
+    assert ei.value.code == _native.ERR_INTERRUPTED and len(polls) == 2     # polled every 50 iterations (:364)
+    lines = []
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), True, seed=1, devices=[0, 0],
+                                               **{"print": lines.append})
+    text = "".join(lines)
+    assert "Points: 900, Pairs per iteration: 404550" in text and "2 row blocks" in text
+    assert "Iter " in text and ", k=" in text and got.iterations > 0
+
+
+def test_config4_size_two_blocks_equal_one_block_and_host_overhead():
+    """BASELINE config 4 (N = 50 000, ndim 3, 90 % missing), generated block by block in HBM: two row blocks on the
+    one GPU against one block, bit for bit; and the loop's wall time against block 0's own kernel time -- what
+    the host adds per iteration (launches, event barriers, thread hand-offs) must stay below 10 % of the stage
+    time."""
+    torch = pytest.importorskip("torch")
+    from topolow_amd import sharded
+    n, dim, iters = 50000, 3, 12
+    results = {}
+    for blocks in (1, 2):
+        rows = _native.shard_rows(n, blocks)
+        backs = [sharded.HipBackend(n, dim, rb, re_, 0) for rb, re_ in rows]
+        scale = None
+        for b, bk in enumerate(backs):
+            _ne, scale = sharded.load_synthetic_block(bk, n, 3, 0.9, 12345, b, len(backs), rows=rows[b])
+        torch.cuda.synchronize()
+        rng = np.random.Generator(np.random.PCG64(999))
+        init = np.zeros((n, dim))
+        init[1:] = np.cumsum(rng.uniform(0.0, 2.0 * scale / n, size=(n - 1, dim)), axis=0)
+        ss = [bk.session for bk in backs]
+        _native.run_sharded(ss, init, 3, 5.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 7)               # warm-up
+        res = _native.run_sharded(ss, init, iters, 5.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 7)
+        prof = _native.run_sharded(ss, init, iters, 5.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 7, profile=True)
+        assert np.array_equal(prof.positions, res.positions)
+        results[blocks] = (res, prof)
+        for s in ss:
+            s.close()
+    (r1, p1), (r2, p2) = results[1], results[2]
+    assert np.array_equal(r1.positions, r2.positions) and r1.iterations == r2.iterations == iters
+    assert r1.final_mae == pytest.approx(r2.final_mae, rel=1e-6)
+    # one block: everything the loop does besides block 0's kernels is host / barrier overhead
+    busy = p1.info["stage_kernel_seconds"] + p1.info["check_kernel_seconds"]
+    assert r1.info["loop_seconds"] <= 1.10 * busy, (r1.info, p1.info)
+    # two blocks share the GPU: their kernels overlap, so the loop must not take longer than one block's
+    assert r2.info["loop_seconds"] <= 1.10 * r1.info["loop_seconds"], (r1.info, r2.info)

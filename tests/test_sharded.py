@@ -17,7 +17,8 @@ from topolow_amd import _native, core, sharded, synthetic
 
 
 class ModelBackend:
-    """CPU stand-in for sharded.HipBackend: same interface, slab model + oracle MAE."""
+    """CPU stand-in for sharded.HipBackend: same interface; the slab model moves the points, the oracle
+    scores them, and the controller is the library's own (host helper, no GPU), fed one check at a time."""
 
     def __init__(self, call, row_begin, row_end, edge_slice):
         self.call = call
@@ -34,31 +35,56 @@ class ModelBackend:
         t[: self.n] = torch.from_numpy(np.asarray(pos_np, dtype=np.float64))
         return t
 
-    def to_host(self, t):
-        return t[: self.n].numpy().copy()
-
-    def begin(self, n_iter, k0, cool, c_rep, seed):
+    def begin(self, pos0, n_iter, k0, cool, c_rep, eps, window, freq, seed):
         self.seed, self.c_rep = seed, c_rep
+        self.k0, self.eps, self.window = k0, eps, window
+        self.maes, self.iters, self.ks = [], [], []
+        self.best = np.array(pos0, dtype=np.float64)
+        self.state = dict(best_mae=np.finfo(np.float64).max, best_k=k0, best_iter=0)
+        self.stopped, self.iters_run, self.bad = False, 0, 0
 
     def stage(self, pos_in, pos_out, it, slot, stages, k):
+        if self.stopped:      # like the kernels: no-ops once the controller said stop
+            return
         c = self.call
         rg = _native.slab_plan(self.n, stages, self.seed, it)[slot].reshape(2, 2)
         rg = [r for r in rg if r[1] > r[0]]
         new = slab_model.stage(pos_in[: self.n].numpy(), c.dissimilarity_matrix, c.threshold_matrix,
                                c.degrees, rg, k, self.c_rep, "f64")
         pos_out[self.rb:self.re] = torch.from_numpy(new[self.rb:self.re])
+        if not np.isfinite(new[self.rb:self.re]).all() and not self.bad:
+            self.bad = it + 1
+        self.iters_run = max(self.iters_run, it + 1)
 
-    def edge_error(self, pos):
+    def check_partial(self, pos):
         c = self.call
         sl = self.edges
-        return orc.edge_error(pos[: self.n].numpy(), c.edge_i[sl], c.edge_j[sl], c.edge_dist[sl],
-                              c.edge_thresh[sl])
+        s_, c_ = orc.edge_error(pos[: self.n].numpy(), c.edge_i[sl], c.edge_j[sl], c.edge_dist[sl],
+                                c.edge_thresh[sl])
+        return torch.tensor([0.0, 0.0] if self.stopped else [s_, float(c_)], dtype=torch.float64)
 
-    def all_finite(self, pos):
-        return bool(torch.isfinite(pos[: self.n]).all())
+    def controller_step(self, total2, pos, iter1, k_after):
+        if self.stopped:
+            return
+        s_, c_ = float(total2[0]), float(total2[1])
+        self.maes.append(s_ / c_ if c_ > 0 else 0.0); self.iters.append(iter1); self.ks.append(k_after)
+        r = _native.controller_script(self.maes, self.iters, self.ks, self.k0, self.window, self.eps)
+        if r["snapshots"][len(self.maes) - 1]:
+            self.best = pos[: self.n].numpy().copy()
+        self.state = r
+        if r["stopped_at"] >= 0:
+            self.stopped = True
+            self.iters_run = iter1
 
-    def clone(self, pos):
-        return pos.clone()
+    def poll(self):
+        return self.stopped, self.iters_run
+
+    def first_nonfinite(self):
+        return self.bad
+
+    def finish(self):
+        return _native.NativeResult(self.best, self.stopped, self.state["best_iter"], self.state["best_mae"],
+                                    self.state["best_k"], dict(n_checks=len(self.maes)))
 
     def synchronize(self):
         pass

@@ -41,7 +41,7 @@ PRINT_CB = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
 class TopolowOptions(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("schedule", C.c_int32), ("precision", C.c_int32),
                 ("slab_stages", C.c_int32), ("device", C.c_int32), ("gs_max_n", C.c_int32),
-                ("n_devices", C.c_int32), ("reserved", C.c_int32 * 4),
+                ("n_devices", C.c_int32), ("keep_labels", C.c_int32), ("reserved", C.c_int32 * 3),
                 ("interrupt_cb", INTERRUPT_CB), ("interrupt_user", C.c_void_p),
                 ("print_cb", PRINT_CB), ("print_user", C.c_void_p), ("devices", C.POINTER(C.c_int32))]
 
@@ -50,7 +50,14 @@ class TopolowRunStats(C.Structure):
     _fields_ = [("schedule_used", C.c_int32), ("precision_used", C.c_int32),
                 ("iterations_run", C.c_int32), ("n_checks", C.c_int32),
                 ("device_seconds", C.c_double), ("total_seconds", C.c_double),
-                ("stage_launches", C.c_int64), ("reserved", C.c_int64 * 4)]
+                ("stage_launches", C.c_int64), ("setup_seconds", C.c_double), ("reserved", C.c_int64 * 3)]
+
+
+class TopolowShardStats(C.Structure):
+    _fields_ = [("blocks", C.c_int32), ("iterations_run", C.c_int32), ("n_checks", C.c_int32),
+                ("reserved0", C.c_int32), ("loop_seconds", C.c_double), ("total_seconds", C.c_double),
+                ("stage_kernel_seconds", C.c_double), ("check_kernel_seconds", C.c_double),
+                ("stage_launches", C.c_int64), ("exchanges", C.c_int64), ("reserved", C.c_int64 * 4)]
 
 
 class TopolowProblem(C.Structure):
@@ -141,6 +148,30 @@ def load() -> C.CDLL:
     i64p = C.POINTER(C.c_int64)
     lib.topolow_cv_fold.argtypes = [C.POINTER(TopolowCellList), i64p, C.c_int64, C.c_int32, C.c_int32, ip, ip,
                                     ip, ip, dp, ip, i64p, ip, ip, dp, i64p, dp]
+    lib.topolow_session_set_relabel.restype = C.c_int
+    lib.topolow_session_set_relabel.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+    lib.topolow_session_labels.restype = C.c_int
+    lib.topolow_session_labels.argtypes = [C.c_void_p, ip]
+    lib.topolow_session_check_partial.restype = C.c_int
+    lib.topolow_session_check_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.topolow_session_controller_step.restype = C.c_int
+    lib.topolow_session_controller_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
+                                                    C.c_char_p, C.c_size_t]
+    lib.topolow_session_first_nonfinite.restype = C.c_int
+    lib.topolow_session_first_nonfinite.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.topolow_shard_rows.restype = C.c_int32
+    lib.topolow_shard_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, ip, ip]
+    lib.topolow_optimize_layout_exact_sharded.restype = C.c_int
+    lib.topolow_optimize_layout_exact_sharded.argtypes = [
+        dp, C.c_int32, C.c_int32, dp, ip, ip, ip, ip, dp, ip, C.c_int64,
+        C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
+        C.c_int32, C.POINTER(TopolowOptions), dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp,
+        C.POINTER(TopolowShardStats), C.c_char_p, C.c_size_t]
+    lib.topolow_sessions_run_sharded.restype = C.c_int
+    lib.topolow_sessions_run_sharded.argtypes = [
+        C.POINTER(C.c_void_p), C.c_int32, dp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+        C.c_int32, C.c_int32, C.c_uint64, C.c_int32, INTERRUPT_CB, C.c_void_p, C.c_int32, dp,
+        C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.POINTER(TopolowShardStats), C.c_char_p, C.c_size_t]
     lib.topolow_cell_list_index.restype = C.c_int
     lib.topolow_cell_list_index.argtypes = [C.c_int32, C.c_int64, ip, ip, i64p, i64p, i64p]
     lib.topolow_session_check_trace.restype = C.c_int
@@ -212,6 +243,8 @@ def load() -> C.CDLL:
     lib.topolow_slab_plan.argtypes = [C.c_int32, C.c_int32, C.c_uint64, C.c_int32, ip, C.c_int32]
     lib.topolow_slab_stages_for_k.restype = C.c_int32
     lib.topolow_slab_stages_for_k.argtypes = [C.c_double]
+    lib.topolow_slab_stages_at.restype = C.c_int32
+    lib.topolow_slab_stages_at.argtypes = [C.c_int32, C.c_double]
     lib.topolow_gs_pair_order.restype = C.c_int64
     lib.topolow_gs_pair_order.argtypes = [C.c_int32, C.c_uint64, C.c_int32, ip]
     lib.topolow_encode_target.restype = C.c_uint32
@@ -263,6 +296,7 @@ def make_options(**kw) -> TopolowOptions:
     o.slab_stages = int(cfg.get("slab_stages", 0) or 0)
     o.device = int(cfg.get("device", -1))
     o.gs_max_n = int(cfg.get("gs_max_n", 0) or 0)
+    o.keep_labels = int(bool(cfg.get("keep_labels", False)))
     cb = cfg.get("interrupt")
     if cb is not None:   # Python callable() -> truthy to stop; keep a reference alive on the struct
         o._cb_keepalive = INTERRUPT_CB(lambda _user: 1 if cb() else 0)
@@ -321,7 +355,7 @@ def optimize_layout_exact_arrays(initial_positions, dissimilarity_matrix, thresh
                 precision={PRECISION_F32: "f32", PRECISION_F64: "f64"}.get(stats.precision_used),
                 iterations_run=stats.iterations_run, n_checks=stats.n_checks,
                 device_seconds=stats.device_seconds, total_seconds=stats.total_seconds,
-                stage_launches=stats.stage_launches, seed=int(opt.seed))
+                setup_seconds=stats.setup_seconds, stage_launches=stats.stage_launches, seed=int(opt.seed))
     return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value),
                         float(fmae.value), float(fk.value), info)
 
@@ -441,6 +475,84 @@ def cv_fold(cells: CellList, picks, preserve_order: bool, named: bool):
             et[:e].copy(), hi[:h].copy(), hj[:h].copy(), ht[:h].copy(), float(vmax.value))
 
 
+def shard_rows(n: int, blocks: int):
+    """Row blocks of the row-sharded path: list of (row_begin, row_end), empty trailing blocks dropped."""
+    lib = load()
+    used = lib.topolow_shard_rows(int(n), int(blocks), -1, None, None)
+    out = []
+    for b in range(used):
+        rb, re_ = C.c_int32(0), C.c_int32(0)
+        lib.topolow_shard_rows(int(n), int(blocks), b, C.byref(rb), C.byref(re_))
+        out.append((int(rb.value), int(re_.value)))
+    return out
+
+
+def optimize_layout_exact_sharded(initial_positions, degrees, edge_i, edge_j, edge_dist, edge_thresh, n_iter, k0,
+                                  cooling_rate, c_repulsion, relative_epsilon=1e-4, convergence_window=5,
+                                  convergence_check_freq=3, verbose=False, dissimilarity_matrix=None,
+                                  threshold_matrix=None, devices=(0,), **opt_kw) -> NativeResult:
+    """The `.Call` payload as ONE embedding row-sharded over `devices` (topolow_optimize_layout_exact_sharded).
+    Without the dense matrices the edge list IS the matrix (large problems)."""
+    lib = load()
+    pos0 = _f64F(initial_positions)
+    n, dim = pos0.shape
+    D = _f64F(dissimilarity_matrix) if dissimilarity_matrix is not None else None
+    T = _i32F(threshold_matrix) if threshold_matrix is not None else None
+    deg = np.ascontiguousarray(degrees, dtype=np.int32)
+    ei = np.ascontiguousarray(edge_i, dtype=np.int32)
+    ej = np.ascontiguousarray(edge_j, dtype=np.int32)
+    ed = np.ascontiguousarray(edge_dist, dtype=np.float64)
+    et = np.ascontiguousarray(edge_thresh, dtype=np.int32)
+    out = np.zeros((n, dim), dtype=np.float64, order="F")
+    conv, iters = C.c_int32(0), C.c_int32(0)
+    fmae, fk = C.c_double(0.0), C.c_double(0.0)
+    stats = TopolowShardStats()
+    err = C.create_string_buffer(512)
+    opt = make_options(devices=list(devices), **opt_kw)
+    rc = lib.topolow_optimize_layout_exact_sharded(
+        _dp(pos0), n, dim, _dp(D) if D is not None else None, _ip(T) if T is not None else None, _ip(deg),
+        _ip(ei), _ip(ej), _dp(ed), _ip(et), int(ei.shape[0]), int(n_iter), float(k0), float(cooling_rate),
+        float(c_repulsion), float(relative_epsilon), int(convergence_window), int(convergence_check_freq),
+        int(bool(verbose)), C.byref(opt), _dp(out), C.byref(conv), C.byref(iters), C.byref(fmae), C.byref(fk),
+        C.byref(stats), err, len(err))
+    _check(rc, err)
+    info = dict(schedule="slab", blocks=stats.blocks, iterations_run=stats.iterations_run, n_checks=stats.n_checks,
+                loop_seconds=stats.loop_seconds, total_seconds=stats.total_seconds,
+                stage_kernel_seconds=stats.stage_kernel_seconds, check_kernel_seconds=stats.check_kernel_seconds,
+                stage_launches=stats.stage_launches, exchanges=stats.exchanges, seed=int(opt.seed))
+    return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value), float(fmae.value),
+                        float(fk.value), info)
+
+
+def run_sharded(sessions, initial_positions, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon=1e-4,
+                convergence_window=5, convergence_check_freq=3, seed=0, slab_stages=0, interrupt=None,
+                profile=False) -> NativeResult:
+    """ONE embedding over the given row-block sessions (topolow_sessions_run_sharded): one process, one
+    host thread per block, peer-stored position slices, replicated controller."""
+    lib = load()
+    pos0 = _f64F(initial_positions)
+    n, dim = pos0.shape
+    hs = (C.c_void_p * len(sessions))(*[s._h for s in sessions])
+    out = np.zeros((n, dim), dtype=np.float64, order="F")
+    conv, iters = C.c_int32(0), C.c_int32(0)
+    fmae, fk = C.c_double(0.0), C.c_double(0.0)
+    stats = TopolowShardStats()
+    err = C.create_string_buffer(512)
+    cb = INTERRUPT_CB(lambda _u: 1 if interrupt() else 0) if interrupt is not None else INTERRUPT_CB()
+    rc = lib.topolow_sessions_run_sharded(hs, len(sessions), _dp(pos0), int(n_iter), float(k0), float(cooling_rate),
+                                          float(c_repulsion), float(relative_epsilon), int(convergence_window),
+                                          int(convergence_check_freq), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                          int(slab_stages), cb, None, int(bool(profile)), _dp(out), C.byref(conv),
+                                          C.byref(iters), C.byref(fmae), C.byref(fk), C.byref(stats), err, len(err))
+    _check(rc, err)
+    info = dict(schedule="slab", blocks=stats.blocks, iterations_run=stats.iterations_run, n_checks=stats.n_checks,
+                loop_seconds=stats.loop_seconds, stage_kernel_seconds=stats.stage_kernel_seconds,
+                check_kernel_seconds=stats.check_kernel_seconds, stage_launches=stats.stage_launches,
+                exchanges=stats.exchanges)
+    return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value), float(fmae.value),
+                        float(fk.value), info)
+
+
 def est_distances(positions) -> np.ndarray:
     """as.matrix(dist(positions)) (reference R/core.R:474) on the GPU."""
     lib = load()
@@ -464,6 +576,10 @@ def slab_plan(n: int, slab_stages: int, seed: int, it: int) -> np.ndarray:
 
 def slab_stages_for_k(k: float) -> int:
     return int(load().topolow_slab_stages_for_k(float(k)))
+
+
+def slab_stages_at(it: int, k: float) -> int:
+    return int(load().topolow_slab_stages_at(int(it), C.c_double(k)))
 
 
 def gs_pair_order(n: int, seed: int, it: int) -> np.ndarray:
@@ -629,6 +745,17 @@ class Session:
         _check(self.lib.topolow_session_check_trace(self._h, _dp(out), int(n.value), C.byref(n)), err)
         return out[: int(n.value)]
 
+    def set_relabel(self, seed: int):
+        """Store the points in a random order drawn from `seed` (0 = the caller's order); before loading."""
+        _check(self.lib.topolow_session_set_relabel(self._h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                                    self._err, len(self._err)), self._err)
+
+    def labels(self) -> np.ndarray:
+        """session label -> caller's label."""
+        out = np.empty(self.n, dtype=np.int32)
+        self.lib.topolow_session_labels(self._h, _ip(out))
+        return out
+
     def set_schedule(self, schedule: str):
         rc = self.lib.topolow_session_set_schedule(self._h, _SCHEDULES[schedule])
         if rc != OK:
@@ -674,6 +801,23 @@ class Session:
         _check(self.lib.topolow_session_stage(self._h, C.c_void_p(d_pos_in), C.c_void_p(d_pos_out),
                                               int(it), int(stage), int(n_stages), float(k),
                                               self._err, len(self._err)), self._err)
+
+    def check_partial(self, d_pos: int, d_out2: int):
+        """Enqueue this block's share of the convergence MAE on the positions at d_pos: two doubles
+        (sum, count) at the device address d_out2."""
+        _check(self.lib.topolow_session_check_partial(self._h, C.c_void_p(d_pos), C.c_void_p(d_out2),
+                                                      self._err, len(self._err)), self._err)
+
+    def controller_step(self, d_total2: int, d_pos: int, iter1: int, k_after: float):
+        """Enqueue the controller (reference :303-357) on the all-reduced (sum, count) at d_total2."""
+        _check(self.lib.topolow_session_controller_step(self._h, C.c_void_p(d_total2), C.c_void_p(d_pos),
+                                                        int(iter1), float(k_after), self._err,
+                                                        len(self._err)), self._err)
+
+    def first_nonfinite(self) -> int:
+        it = C.c_int32(0)
+        _check(self.lib.topolow_session_first_nonfinite(self._h, C.byref(it)), self._err)
+        return int(it.value)
 
     def edge_error(self, d_pos: int):
         s, c = C.c_double(0.0), C.c_int64(0)

@@ -413,6 +413,9 @@ __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>
 //   st      : run state (nullable): launch is a no-op once st->stopped is set; non-finite
 //             results are reported through st->first_nonfinite
 //   falling_priority: see StageCfg::PRIO
+//   push / n_push: row-sharded runs -- the same rows are also stored into the position buffers of the
+//             other row blocks (peer stores: on another GPU of the node they travel over xGMI), so the
+//             all-gather of the updated slices is part of this kernel's epilogue
 //   ANYTHR = false: the host has checked that NO row of the block holds a threshold target,
 //   so only the cheaper classification is compiled in (fewer registers, one more wave per SIMD).
 template <int DIM, typename real, typename CFG, bool ANYTHR>
@@ -420,7 +423,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
     const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
     const real* __restrict__ pos_in, real* __restrict__ pos_out,
     const float* __restrict__ gplus, const unsigned char* __restrict__ rowflags, RunState* st,
-    SlabRanges rg, int iter1, double k, double c_rep, int falling_priority) {
+    SlabRanges rg, int iter1, double k, double c_rep, int falling_priority,
+    real* const* __restrict__ push, int n_push) {
   if (st != nullptr && st->stopped) return;
   TL_WG_STAMP(0);
   using G = PipeGeom<DIM, real, CFG::CHUNK>;
@@ -510,6 +514,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
 #pragma unroll
       for (int d = 0; d < DIM; ++d) pos_out[(size_t)row * DIM + d] = out[d];
       if (!finite && st != nullptr) atomicMin(&st->first_nonfinite, iter1);
+    }
+    if (n_push > 0 && row < row_end && lane >= 1 && lane <= n_push) {   // lane q serves block q-1
+      real* dst = push[lane - 1];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) dst[(size_t)row * DIM + d] = out[d];
     }
   }
   TL_WG_STAMP(1);
@@ -784,6 +793,59 @@ __global__ __launch_bounds__(kThreads) void edge_error_kernel(
   }
 }
 
+// Row-sharded runs: folds a block's per-workgroup partials into one (sum, count) in a fixed order
+// and stores it into slot `slot` of every block's rank table (peer stores), so that after the
+// cross-block barrier every block's controller reads the same n_ranks entries in the same order.
+__global__ __launch_bounds__(1024) void reduce_push_kernel(
+    const double* __restrict__ part_sum, const unsigned long long* __restrict__ part_cnt, int n_parts,
+    double* const* __restrict__ dst_sum, unsigned long long* const* __restrict__ dst_cnt, int n_dst,
+    int slot, const RunState* st) {
+  if (st != nullptr && st->stopped) return;
+  __shared__ double sh_s[1024];
+  __shared__ unsigned long long sh_c[1024];
+  double s = 0.0;
+  unsigned long long c = 0;
+  for (int p = threadIdx.x; p < n_parts; p += 1024) { s += part_sum[p]; c += part_cnt[p]; }
+  sh_s[threadIdx.x] = s;
+  sh_c[threadIdx.x] = c;
+  __syncthreads();
+  for (int half = 512; half >= 1; half >>= 1) {
+    if (threadIdx.x < half) {
+      sh_s[threadIdx.x] += sh_s[threadIdx.x + half];
+      sh_c[threadIdx.x] += sh_c[threadIdx.x + half];
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < n_dst) {
+    dst_sum[threadIdx.x][slot] = sh_s[0];
+    dst_cnt[threadIdx.x][slot] = sh_c[0];
+  }
+}
+
+// A block's partials folded into two doubles (sum, count) in a fixed order: the operand of the
+// multi-process driver's all-reduce.
+__global__ __launch_bounds__(1024) void reduce_total_kernel(
+    const double* __restrict__ part_sum, const unsigned long long* __restrict__ part_cnt, int n_parts,
+    double* __restrict__ out2, const RunState* st) {
+  if (st != nullptr && st->stopped) { if (threadIdx.x == 0) { out2[0] = 0.0; out2[1] = 0.0; } return; }
+  __shared__ double sh_s[1024];
+  __shared__ unsigned long long sh_c[1024];
+  double s = 0.0;
+  unsigned long long c = 0;
+  for (int p = threadIdx.x; p < n_parts; p += 1024) { s += part_sum[p]; c += part_cnt[p]; }
+  sh_s[threadIdx.x] = s;
+  sh_c[threadIdx.x] = c;
+  __syncthreads();
+  for (int half = 512; half >= 1; half >>= 1) {
+    if (threadIdx.x < half) {
+      sh_s[threadIdx.x] += sh_s[threadIdx.x + half];
+      sh_c[threadIdx.x] += sh_c[threadIdx.x + half];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = sh_s[0]; out2[1] = (double)sh_c[0]; }
+}
+
 // Single-block controller step: reduces the partials in a fixed order, runs the reference's
 // three-way classification, snapshots positions when the error improved, advances the run
 // state and mirrors it to the pinned host mailbox.
@@ -794,14 +856,18 @@ __global__ __launch_bounds__(kCtlThreads) void controller_kernel(
     RunState* st, RunState* mailbox, const double* __restrict__ part_sum,
     const unsigned long long* __restrict__ part_cnt, int n_parts, const real* __restrict__ pos,
     real* __restrict__ best_pos, long long n_values, int iter1, double k_after,
-    double* __restrict__ trace, int trace_cap) {
+    double* __restrict__ trace, int trace_cap, const double* __restrict__ total2) {
+  // total2 != nullptr: the error sum and count arrive already reduced (two doubles: the row-sharded
+  // multi-process driver all-reduces them over RCCL); the partial arrays are ignored
   if (st->stopped) return;
   __shared__ double sh_s[kCtlThreads];
   __shared__ unsigned long long sh_c[kCtlThreads];
   __shared__ int sh_action;
   double s = 0.0;
   unsigned long long c = 0;
-  for (int p = threadIdx.x; p < n_parts; p += kCtlThreads) { s += part_sum[p]; c += part_cnt[p]; }
+  if (total2 == nullptr)
+    for (int p = threadIdx.x; p < n_parts; p += kCtlThreads) { s += part_sum[p]; c += part_cnt[p]; }
+  else if (threadIdx.x == 0) { s = total2[0]; c = (unsigned long long)total2[1]; }
   sh_s[threadIdx.x] = s;
   sh_c[threadIdx.x] = c;
   __syncthreads();
@@ -851,13 +917,16 @@ __global__ __launch_bounds__(kCtlThreads) void controller_kernel(
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void encode_dense_kernel(
     const double* __restrict__ D, const int* __restrict__ T, int n, int row_begin, int row_end,
-    int ld, uint32_t* __restrict__ out) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  const int i = row_begin + blockIdx.y;
+    int ld, uint32_t* __restrict__ out, const int* __restrict__ perm) {
+  // grid: x = row of the block (no 65535 limit), y = 256-column group
+  // perm (nullable): session label -> caller's label (the block is stored in session labels)
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  const int i = row_begin + blockIdx.x;
   if (c >= ld || i >= row_end) return;
   uint32_t w = kInfWord;  // diagonal and padding: see relax_common.h
   if (c < n && c != i) {
-    const int lo = i < c ? i : c, hi = i < c ? c : i;
+    const int oi = perm ? perm[i] : i, oc = perm ? perm[c] : c;
+    const int lo = oi < oc ? oi : oc, hi = oi < oc ? oc : oi;
     const size_t cell = (size_t)lo + (size_t)hi * n;
     w = encode_target(D[cell], T[cell]);
   }
@@ -917,8 +986,8 @@ __global__ __launch_bounds__(kThreads) void row_flags_kernel(const uint32_t* __r
 
 __global__ __launch_bounds__(kThreads) void fill_unmeasured_kernel(
     int n, int row_begin, int row_end, int ld, uint32_t* __restrict__ out) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  const int i = row_begin + blockIdx.y;
+  const int c = blockIdx.y * kThreads + threadIdx.x;   // grid: x = row, y = 256-column group
+  const int i = row_begin + blockIdx.x;
   if (c >= ld || i >= row_end) return;
   out[(size_t)(i - row_begin) * ld + c] = kInfWord;
 }
@@ -926,11 +995,13 @@ __global__ __launch_bounds__(kThreads) void fill_unmeasured_kernel(
 __global__ __launch_bounds__(kThreads) void scatter_edges_kernel(
     const int* __restrict__ ei, const int* __restrict__ ej, const double* __restrict__ ed,
     const int* __restrict__ ec, long long n_edges, int n, int row_begin, int row_end, int ld,
-    uint32_t* __restrict__ out) {
+    uint32_t* __restrict__ out, const int* __restrict__ inv) {
+  // inv (nullable): caller's label -> session label
   const long long e = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (e >= n_edges) return;
-  const int a = ei[e], b = ej[e];
+  int a = ei[e], b = ej[e];
   if (a == b || a < 0 || b < 0 || a >= n || b >= n) return;
+  if (inv != nullptr) { a = inv[a]; b = inv[b]; }
   const uint32_t w = encode_target(ed[e], ec[e]);
   if (a >= row_begin && a < row_end) out[(size_t)(a - row_begin) * ld + b] = w;
   if (b >= row_begin && b < row_end) out[(size_t)(b - row_begin) * ld + a] = w;
@@ -940,8 +1011,8 @@ __global__ __launch_bounds__(kThreads) void scatter_edges_kernel(
 // positions: n x dim row-major f64; out: n x n f64 (symmetric, so layout-agnostic).
 __global__ __launch_bounds__(kThreads) void pdist_kernel(const double* __restrict__ pos, int n,
                                                          int dim, double* __restrict__ out) {
-  const int j = blockIdx.x * kThreads + threadIdx.x;
-  const int i = blockIdx.y;
+  const int j = blockIdx.y * kThreads + threadIdx.x;   // grid: x = row, y = 256-column group
+  const int i = blockIdx.x;
   if (j >= n) return;
   double s = 0.0;
   for (int d = 0; d < dim; ++d) {

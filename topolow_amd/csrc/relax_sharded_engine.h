@@ -1,0 +1,168 @@
+// topolow_amd/csrc/relax_sharded_engine.h -- row-sharded relaxation of ONE embedding over several
+// row-block sessions, driven from one process (an R session is one process: reference
+// src/RcppExports.cpp:16-39).  Implementation fragment of topolow_relax.hip (uses its session type and
+// launch helpers; included inside its anonymous namespace).
+//
+// Layout: block b owns rows [row_begin_b, row_end_b) of the encoded target
+// matrix and moves only its own points; every block keeps ALL n positions (they are tiny).  Per slab
+// stage:
+//   * block b's stage kernel writes its updated rows into its own next-position buffer AND, from the
+//     same epilogue, into the next-position buffer of every other block (peer stores -- over xGMI when
+//     the blocks sit on different GPUs): the all-gather of the position slices is fused into the
+//     kernel, there is no separate collective and no staging copy;
+//   * a cross-block barrier out of HIP events: every block records an event behind its stage kernel
+//     and makes its stream wait for the events of the others.  Peer-written data is consumed only by
+//     kernels that START after that wait -- kernel-boundary visibility, the guarantee HIP gives for
+//     ordinary (coarse-grained) device memory; nothing spins inside a kernel on a remote flag.
+// Per convergence check each block reduces its parity share of the measured pairs, folds the
+// partials into one (sum, count) and peer-stores it into a slot of every block's rank table; after
+// one more barrier every block runs the SAME controller on the SAME numbers in the same order, so
+// the decisions (stop / snapshot) are replicated without any host round trip.
+// One host thread per block enqueues that block's work (the event waits are per pair of blocks, a
+// single thread would issue P^2 of them per stage); threads meet in a spin barrier between "record"
+// and "wait" so an event is always recorded before anyone waits on it.  The calling thread is block
+// 0's thread: only it polls the caller's interrupt callback (R's API is main-thread only).
+
+struct ShardedAbortableBarrier {
+  std::atomic<int> count{0};
+  std::atomic<int> sense{0};
+  std::atomic<bool> failed{false};
+  int n;
+  explicit ShardedAbortableBarrier(int n_) : n(n_) {}
+  // false: some thread failed (it never arrives); the caller must unwind
+  bool wait() {
+    const int s = sense.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+      count.store(0, std::memory_order_relaxed);
+      sense.store(s ^ 1, std::memory_order_release);
+      return !failed.load(std::memory_order_acquire);
+    }
+    int spins = 0;
+    while (sense.load(std::memory_order_acquire) == s) {
+      if (failed.load(std::memory_order_acquire)) return false;
+      if (++spins > 4000) std::this_thread::yield();
+    }
+    return !failed.load(std::memory_order_acquire);
+  }
+  void fail() { failed.store(true, std::memory_order_release); }
+};
+
+struct ShardedRun {
+  std::vector<topolow_session*> ss;
+  int P = 0;
+  int n_iter = 0, check_freq = 3;
+  double k0 = 0, cooling = 0;
+  int fixed_stages = 0;
+  std::vector<std::array<hipEvent_t, 2>> ev;
+  ShardedAbortableBarrier* bar = nullptr;
+  std::atomic<int> flag[2];      // published by block 0's thread before barrier g (slot g & 1): bit 0 stop, bit 1 interrupt
+  int32_t (*interrupt_cb)(void*) = nullptr;
+  void* interrupt_user = nullptr;
+  std::mutex err_mu;
+  HipError first_error{TOPOLOW_OK, ""};
+  // results of the loop
+  int iters_enqueued = 0;
+  bool interrupted = false;
+  long long exchanges = 0;
+};
+
+// One block's enqueue loop (thread r).  Throws HipError; the caller marks the barrier failed.
+inline void sharded_worker(ShardedRun& R, int r) {
+  topolow_session* s = R.ss[r];
+  HIP_TRY(hipSetDevice(s->device));
+  long long g = 0;          // exchange counter, identical in every thread
+  int seen = 0;             // flag value read at the last exchange, identical in every thread
+  auto exchange = [&]() -> bool {
+    HIP_TRY(hipEventRecord(R.ev[r][g & 1], s->stream));
+    if (r == 0) {
+      int f = s->mailbox->stopped ? 1 : 0;
+      if (R.interrupted) f |= 2;
+      R.flag[g & 1].store(f, std::memory_order_release);
+    }
+    if (!R.bar->wait()) return false;
+    for (int p = 0; p < R.P; ++p)
+      if (p != r) HIP_TRY(hipStreamWaitEvent(s->stream, R.ev[p][g & 1], 0));
+    seen = R.flag[g & 1].load(std::memory_order_acquire);
+    ++g;
+    return true;
+  };
+  int cur = 0;
+  double k = R.k0;
+  int iter = 0;
+  for (; iter < R.n_iter; ++iter) {
+    if (seen != 0) break;
+    if (r == 0 && R.interrupt_cb != nullptr && iter > 0 && iter % 50 == 0 && !R.interrupted)   // reference :364
+      R.interrupted = R.interrupt_cb(R.interrupt_user) != 0;   // published at the next exchange
+    const int stages = R.fixed_stages > 0 ? R.fixed_stages : slab_stages_at(iter, k);
+    const SlabGeom geo = slab_geom(s->n, stages);
+    for (int slot = 0; slot < geo.n_stages; ++slot) {
+      const SlabRanges rg = slab_ranges(geo, s->seed, iter, slot);
+      TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[cur].p, s->pos[cur ^ 1].p, s->state.p, rg, iter + 1, k,
+                      s->push_tab[cur ^ 1].p, s->n_push);
+      if (!exchange()) return;
+      cur ^= 1;
+    }
+    k *= (1.0 - R.cooling);   // reference :289
+    if ((iter + 1) % R.check_freq == 0 || iter == R.n_iter - 1) {   // reference :294
+      {
+        ProfScope prof(s, &s->prof_check);
+        TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[cur].p, s->state.p);
+        hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
+                           error_parts(s), s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, s->rank, s->state.p);
+        HIP_TRY(hipGetLastError());
+      }
+      if (!exchange()) return;
+      ProfScope prof(s, &s->prof_check);
+      launch_controller(s, s->pos[cur].p, iter + 1, k, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
+    }
+  }
+  s->cur = cur;
+  if (r == 0) { R.iters_enqueued = iter; R.exchanges = g; }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+}
+
+// Wires `count` loaded sessions (row blocks tiling [0, n) in order, same n / ndim / precision) into one
+// another: peer access between their devices, push tables, rank tables.
+inline void sharded_wire(std::vector<topolow_session*>& ss) {
+  const int P = (int)ss.size();
+  for (int a = 0; a < P; ++a)
+    for (int b = 0; b < P; ++b) {
+      if (ss[a]->device == ss[b]->device) continue;
+      int can = 0;
+      HIP_TRY(hipDeviceCanAccessPeer(&can, ss[a]->device, ss[b]->device));
+      if (!can) throw HipError{TOPOLOW_ERR_UNSUPPORTED, "row-sharded run: the GPUs cannot access each other's memory"};
+      HIP_TRY(hipSetDevice(ss[a]->device));
+      const hipError_t e = hipDeviceEnablePeerAccess(ss[b]->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+      (void)hipGetLastError();
+    }
+  for (int a = 0; a < P; ++a) {
+    topolow_session* s = ss[a];
+    HIP_TRY(hipSetDevice(s->device));
+    s->n_ranks = P;
+    s->rank = a;
+    s->n_push = P - 1;
+    for (int b2 = 0; b2 < 2; ++b2) {
+      std::vector<void*> tab;
+      for (int q = 0; q < P; ++q) if (q != a) tab.push_back((void*)ss[q]->pos[b2].p);
+      s->push_tab[b2].alloc(tab.size());
+      if (!tab.empty())
+        HIP_TRY(hipMemcpy(s->push_tab[b2].p, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
+    }
+    s->rank_sum.alloc(P);
+    s->rank_cnt.alloc(P);
+    HIP_TRY(hipMemset(s->rank_sum.p, 0, sizeof(double) * P));
+    HIP_TRY(hipMemset(s->rank_cnt.p, 0, sizeof(unsigned long long) * P));
+  }
+  for (int a = 0; a < P; ++a) {
+    topolow_session* s = ss[a];
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<double*> ts;
+    std::vector<unsigned long long*> tc;
+    for (int q = 0; q < P; ++q) { ts.push_back(ss[q]->rank_sum.p); tc.push_back(ss[q]->rank_cnt.p); }
+    s->rsum_tab.alloc(P);
+    s->rcnt_tab.alloc(P);
+    HIP_TRY(hipMemcpy(s->rsum_tab.p, ts.data(), P * sizeof(double*), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->rcnt_tab.p, tc.data(), P * sizeof(unsigned long long*), hipMemcpyHostToDevice));
+  }
+}

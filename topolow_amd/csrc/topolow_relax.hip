@@ -15,9 +15,13 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <array>
+#include <atomic>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/topolow_relax.h"
@@ -131,6 +135,53 @@ double now_s() {
       .count();
 }
 
+// Splits [0, n) over a few host threads (the one-shot call's host passes over 10^7..10^8 edges);
+// small ranges run on the calling thread.  fn(begin, end) must be thread-safe.
+template <typename Fn>
+void host_parallel(size_t n, Fn fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t workers = std::max<size_t>(1, std::min<size_t>({n / (1u << 18), (size_t)(hw ? hw : 1), (size_t)16}));
+  if (workers <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> pool;
+  const size_t step = (n + workers - 1) / workers;
+  for (size_t w = 0; w < workers; ++w) {
+    const size_t lo = w * step, hi = std::min(n, lo + step);
+    if (lo >= hi) break;
+    pool.emplace_back([=, &fn] { fn(lo, hi); });
+  }
+  for (auto& t : pool) t.join();
+}
+
+// Is the edge list exactly the measured strict-upper-triangle of the dense inputs (same pairs, same
+// targets, same threshold codes)?  Host only, a few threads: one streaming pass over the upper
+// triangle to count its finite cells, one gather per edge.  (A pair listed twice is not detected here;
+// the caller cross-checks the count on the device.)
+bool edges_are_the_matrix(const double* D, const int32_t* T, int n, const int32_t* ei, const int32_t* ej,
+                          const double* ed, const int32_t* et, int64_t n_edges) {
+  std::atomic<long long> finite{0};
+  host_parallel((size_t)n, [&](size_t lo, size_t hi) {   // columns; work grows with j, close enough
+    long long c = 0;
+    for (size_t j = lo; j < hi; ++j) {
+      const double* col = D + j * (size_t)n;
+      for (size_t i = 0; i < j; ++i) c += std::isfinite(col[i]) ? 1 : 0;
+    }
+    finite.fetch_add(c);
+  });
+  if (finite.load() != (long long)n_edges) return false;
+  std::atomic<bool> ok{true};
+  host_parallel((size_t)n_edges, [&](size_t lo, size_t hi) {
+    for (size_t e = lo; e < hi; ++e) {
+      const int a = ei[e], b = ej[e];
+      if (a < 0 || b <= a || b >= n) { ok.store(false); return; }
+      const size_t cell = (size_t)a + (size_t)b * n;
+      const int tc = T[cell], ec = et[e];
+      const int tn = tc == 0 ? 0 : (tc == 1 ? 1 : -1), en = ec == 0 ? 0 : (ec == 1 ? 1 : -1);
+      if (!(D[cell] == ed[e]) || !std::isfinite(ed[e]) || tn != en) { ok.store(false); return; }
+    }
+  });
+  return ok.load();
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -150,6 +201,13 @@ struct topolow_session {
   int held = -1;
   bool serial_checks = false;   // TOPOLOW_SERIAL_CHECKS=1: keep every check on the main stream
 
+  // Session labels.  With a relabelling (topolow_session_set_relabel) the session stores point
+  // perm[q] of the caller as its point q, so that a slab -- a run of consecutive session labels -- is
+  // a random subset of the caller's points instead of a run of consecutive ones (which lie next to
+  // each other on the reference's random-walk start, R/core.R:407-415, and often in the data's own
+  // order).  Every entry point that takes or returns host arrays speaks the CALLER's labels.
+  std::vector<int> perm, inv;      // session -> caller, caller -> session; empty = identity
+  DevBuf<int> d_perm, d_inv;
   DevBuf<uint32_t> enc;
   DevBuf<float> gplus;
   DevBuf<unsigned char> rowflags;
@@ -188,6 +246,14 @@ struct topolow_session {
   long long stage_launches = 0;
   std::deque<hipEvent_t> pending;
   std::vector<hipEvent_t> event_pool;
+  // row-sharded engine (topolow_sessions_run_sharded): this block's view of the other blocks
+  DevBuf<void*> push_tab[2];           // [b]: the other blocks' position buffer b (device pointers)
+  int n_push = 0;
+  DevBuf<double> rank_sum;             // one (sum, count) slot per block, written by every block
+  DevBuf<unsigned long long> rank_cnt;
+  DevBuf<double*> rsum_tab;            // every block's rank_sum / rank_cnt (self included)
+  DevBuf<unsigned long long*> rcnt_tab;
+  int n_ranks = 0, rank = 0;
   // profiling (roofline accounting)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_stage, prof_check;
@@ -291,7 +357,7 @@ int slab_variant() {
 
 template <int DIM, typename real, typename CFG>
 void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState* st,
-                       SlabRanges rg, int iter1, double k) {
+                       SlabRanges rg, int iter1, double k, const void* push, int n_push) {
   const int blocks = (s->rows() + CFG::ROWS - 1) / CFG::ROWS;
 #ifdef TOPOLOW_TUNING
   g_stamps.arm(blocks);
@@ -309,7 +375,7 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
     const int falling = blocks <= resident[which] ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), 0, s->stream, s->enc.p, s->ld,
                        s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
-                       s->rowflags.p, st, rg, iter1, k, s->c_rep, falling);
+                       s->rowflags.p, st, rg, iter1, k, s->c_rep, falling, (real* const*)push, n_push);
   };
   if (s->any_threshold) {
     // The instance that also carries the ">" / "<" classification needs more registers: from
@@ -327,23 +393,23 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
 
 template <int DIM>
 void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st, SlabRanges rg,
-                  int iter1, double k) {
+                  int iter1, double k, const void* push = nullptr, int n_push = 0) {
   if (s->rows() <= 0) return;
   ProfScope prof(s, &s->prof_stage);
   if (s->precision == TOPOLOW_PRECISION_F64) {
-    launch_stage_pipe<DIM, double, StageCfg<256, 2, 0, 1>>(s, pin, pout, st, rg, iter1, k);
+    launch_stage_pipe<DIM, double, StageCfg<256, 2, 0, 1>>(s, pin, pout, st, rg, iter1, k, push, n_push);
   } else {
 #ifdef TOPOLOW_TUNING
     switch (slab_variant()) {
-      case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 1, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 4>>(s, pin, pout, st, rg, iter1, k); break;
-      case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 1, 5>>(s, pin, pout, st, rg, iter1, k); break;
-      case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 7>>(s, pin, pout, st, rg, iter1, k); break;
-      default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k); break;
+      case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
+      case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 1, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
+      case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 4>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
+      case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 1, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
+      case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 7>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
+      default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
     }
 #else
-    launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k);
+    launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push);
 #endif
   }
   HIP_TRY(hipGetLastError());
@@ -388,16 +454,20 @@ void launch_edge_error(topolow_session* s, const void* pos, const RunState* st) 
   HIP_TRY(hipGetLastError());
 }
 
-void launch_controller(topolow_session* s, const void* pos, int iter1, double k_after) {
+// psum / pcnt / nparts: the partials to reduce (default: the block's own error-kernel partials)
+void launch_controller(topolow_session* s, const void* pos, int iter1, double k_after,
+                       const double* psum = nullptr, const unsigned long long* pcnt = nullptr, int nparts = 0,
+                       const double* total2 = nullptr) {
   const long long nv = (long long)s->n * s->dim;
+  if (psum == nullptr && total2 == nullptr) { psum = s->part_sum.p; pcnt = s->part_cnt.p; nparts = error_parts(s); }
   if (s->precision == TOPOLOW_PRECISION_F64) {
     hipLaunchKernelGGL((controller_kernel<double>), dim3(1), dim3(kCtlThreads), 0, s->stream,
-                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, error_parts(s),
-                       (const double*)pos, (double*)s->best.p, nv, iter1, k_after, s->trace_dev, s->trace_cap);
+                       s->state.p, s->mailbox_dev, psum, pcnt, nparts,
+                       (const double*)pos, (double*)s->best.p, nv, iter1, k_after, s->trace_dev, s->trace_cap, total2);
   } else {
     hipLaunchKernelGGL((controller_kernel<float>), dim3(1), dim3(kCtlThreads), 0, s->stream,
-                       s->state.p, s->mailbox_dev, s->part_sum.p, s->part_cnt.p, error_parts(s),
-                       (const float*)pos, (float*)s->best.p, nv, iter1, k_after, s->trace_dev, s->trace_cap);
+                       s->state.p, s->mailbox_dev, psum, pcnt, nparts,
+                       (const float*)pos, (float*)s->best.p, nv, iter1, k_after, s->trace_dev, s->trace_cap, total2);
   }
   HIP_TRY(hipGetLastError());
 }
@@ -408,16 +478,20 @@ void upload_positions(topolow_session* s, const double* host_colmajor, void* dst
   const size_t nv = (size_t)s->pos_rows() * s->dim;
   if (s->precision == TOPOLOW_PRECISION_F64) {
     std::vector<double> tmp(nv, 0.0);
-    for (int i = 0; i < s->n; ++i)
-      for (int d = 0; d < s->dim; ++d) tmp[(size_t)i * s->dim + d] = host_colmajor[i + (size_t)d * s->n];
+    for (int i = 0; i < s->n; ++i) {
+      const int o = s->perm.empty() ? i : s->perm[i];
+      for (int d = 0; d < s->dim; ++d) tmp[(size_t)i * s->dim + d] = host_colmajor[o + (size_t)d * s->n];
+    }
     for (int i = s->n; i < s->pos_rows(); ++i) tmp[(size_t)i * s->dim] = kFarF64;
     HIP_TRY(hipMemcpyAsync(dst, tmp.data(), nv * 8, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   } else {
     std::vector<float> tmp(nv, 0.0f);
-    for (int i = 0; i < s->n; ++i)
+    for (int i = 0; i < s->n; ++i) {
+      const int o = s->perm.empty() ? i : s->perm[i];
       for (int d = 0; d < s->dim; ++d)
-        tmp[(size_t)i * s->dim + d] = (float)host_colmajor[i + (size_t)d * s->n];
+        tmp[(size_t)i * s->dim + d] = (float)host_colmajor[o + (size_t)d * s->n];
+    }
     for (int i = s->n; i < s->pos_rows(); ++i) tmp[(size_t)i * s->dim] = kFarF32;
     HIP_TRY(hipMemcpyAsync(dst, tmp.data(), nv * 4, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -430,15 +504,19 @@ void download_positions(topolow_session* s, const void* src, double* host_colmaj
     std::vector<double> tmp(nv);
     HIP_TRY(hipMemcpyAsync(tmp.data(), src, nv * 8, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    for (int i = 0; i < s->n; ++i)
-      for (int d = 0; d < s->dim; ++d) host_colmajor[i + (size_t)d * s->n] = tmp[(size_t)i * s->dim + d];
+    for (int i = 0; i < s->n; ++i) {
+      const int o = s->perm.empty() ? i : s->perm[i];
+      for (int d = 0; d < s->dim; ++d) host_colmajor[o + (size_t)d * s->n] = tmp[(size_t)i * s->dim + d];
+    }
   } else {
     std::vector<float> tmp(nv);
     HIP_TRY(hipMemcpyAsync(tmp.data(), src, nv * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    for (int i = 0; i < s->n; ++i)
+    for (int i = 0; i < s->n; ++i) {
+      const int o = s->perm.empty() ? i : s->perm[i];
       for (int d = 0; d < s->dim; ++d)
-        host_colmajor[i + (size_t)d * s->n] = (double)tmp[(size_t)i * s->dim + d];
+        host_colmajor[o + (size_t)d * s->n] = (double)tmp[(size_t)i * s->dim + d];
+    }
   }
 }
 
@@ -456,7 +534,7 @@ void compute_row_flags(topolow_session* s) {
 
 void upload_degrees(topolow_session* s, const int32_t* degrees) {
   std::vector<float> g(s->n);
-  for (int i = 0; i < s->n; ++i) g[i] = (float)degrees[i] + 1.0f;  // reference :137-140
+  for (int i = 0; i < s->n; ++i) g[i] = (float)degrees[s->perm.empty() ? i : s->perm[i]] + 1.0f;  // reference :137-140
   s->gplus.alloc(s->n);
   HIP_TRY(hipMemcpy(s->gplus.p, g.data(), (size_t)s->n * 4, hipMemcpyHostToDevice));
 }
@@ -550,6 +628,8 @@ int guarded(char* errbuf, size_t errlen, F&& body) {
   }
 }
 
+#include "relax_sharded_engine.h"
+
 }  // namespace
 
 // =========================================================================================
@@ -568,6 +648,7 @@ void topolow_default_options(topolow_options* opt) {
   opt->slab_stages = 0;
   opt->device = -1;
   opt->gs_max_n = 0;
+  opt->keep_labels = 0;
   opt->interrupt_cb = nullptr;
   opt->interrupt_user = nullptr;
 }
@@ -583,6 +664,7 @@ double topolow_decode_target(uint32_t bits, int32_t* threshold_code) {
 }
 
 int32_t topolow_slab_stages_for_k(double k) { return slab_stages_for_k(k); }
+int32_t topolow_slab_stages_at(int32_t iter, double k) { return slab_stages_at(iter, k); }
 
 int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t iter,
                           int32_t* ranges_out, int32_t max_stages) {
@@ -682,6 +764,39 @@ void topolow_session_destroy(topolow_session* s) {
   delete s;
 }
 
+int topolow_session_set_relabel(topolow_session* s, uint64_t seed, char* errbuf, size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (s->gplus.p || s->part_sum.p) {
+    set_err(errbuf, errlen, "the relabelling must be chosen before targets, edges or positions are loaded");
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  }
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    s->perm.clear();
+    s->inv.clear();
+    if (seed == 0) return;   // identity
+    const int n = s->n;
+    s->perm.resize(n);
+    s->inv.resize(n);
+    for (int q = 0; q < n; ++q) s->perm[q] = q;
+    for (int q = n - 1; q > 0; --q) {   // Fisher-Yates on the schedule's counter-based stream
+      const uint32_t r = rnd_below(rnd64(seed, 0x7e1abe1ull, (uint64_t)q), (uint32_t)(q + 1));
+      std::swap(s->perm[q], s->perm[r]);
+    }
+    for (int q = 0; q < n; ++q) s->inv[s->perm[q]] = q;
+    s->d_perm.alloc(n);
+    s->d_inv.alloc(n);
+    HIP_TRY(hipMemcpy(s->d_perm.p, s->perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_inv.p, s->inv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  });
+}
+
+int topolow_session_labels(const topolow_session* s, int32_t* session_to_caller) {
+  if (!s || !session_to_caller) return TOPOLOW_ERR_BAD_ARGUMENT;
+  for (int q = 0; q < s->n; ++q) session_to_caller[q] = s->perm.empty() ? q : s->perm[q];
+  return TOPOLOW_OK;
+}
+
 int topolow_session_load_dense(topolow_session* s, const double* D, const int32_t* T,
                                const int32_t* degrees, char* errbuf, size_t errlen) {
   if (!s || !D || !T || !degrees) return TOPOLOW_ERR_BAD_ARGUMENT;
@@ -694,9 +809,9 @@ int topolow_session_load_dense(topolow_session* s, const double* D, const int32_
     dT.alloc(nn);
     HIP_TRY(hipMemcpy(dD.p, D, nn * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dT.p, T, nn * 4, hipMemcpyHostToDevice));
-    dim3 grid((s->ld + kThreads - 1) / kThreads, s->rows());
+    dim3 grid(s->rows(), (s->ld + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(encode_dense_kernel, grid, dim3(kThreads), 0, s->stream, dD.p, dT.p, s->n,
-                       s->row_begin, s->row_end, s->ld, s->enc.p);
+                       s->row_begin, s->row_end, s->ld, s->enc.p, s->perm.empty() ? nullptr : s->d_perm.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
     compute_row_flags(s);
@@ -711,7 +826,7 @@ int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const in
   if (!s || !degrees || n_edges < 0) return TOPOLOW_ERR_BAD_ARGUMENT;
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
-    dim3 grid((s->ld + kThreads - 1) / kThreads, s->rows());
+    dim3 grid(s->rows(), (s->ld + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(fill_unmeasured_kernel, grid, dim3(kThreads), 0, s->stream, s->n,
                        s->row_begin, s->row_end, s->ld, s->enc.p);
     HIP_TRY(hipGetLastError());
@@ -728,7 +843,7 @@ int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const in
       HIP_TRY(hipMemcpyAsync(dc.p, edge_thresh + off, m * 4, hipMemcpyHostToDevice, s->stream));
       hipLaunchKernelGGL(scatter_edges_kernel, dim3((unsigned)((m + kThreads - 1) / kThreads)),
                          dim3(kThreads), 0, s->stream, di.p, dj.p, dd.p, dc.p, (long long)m, s->n,
-                         s->row_begin, s->row_end, s->ld, s->enc.p);
+                         s->row_begin, s->row_end, s->ld, s->enc.p, s->inv.empty() ? nullptr : s->d_inv.p);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(s->stream));
     }
@@ -744,6 +859,10 @@ int32_t topolow_session_encoded_ld(const topolow_session* s) { return s ? s->ld 
 int topolow_session_commit_encoded(topolow_session* s, const int32_t* degrees, char* errbuf,
                                    size_t errlen) {
   if (!s || !degrees) return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (!s->perm.empty()) {
+    set_err(errbuf, errlen, "a block filled by the caller is in the caller's labels: not with a relabelled session");
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  }
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());  // the caller filled the block on another stream
@@ -760,26 +879,6 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
     HIP_TRY(hipSetDevice(s->device));
     s->n_edges = n_edges;
     const size_t m = (size_t)n_edges;
-    s->ei.alloc(m); s->ej.alloc(m); s->ec.alloc(m);
-    std::vector<int8_t> codes(m);
-    for (size_t e = 0; e < m; ++e) {
-      const int c = edge_thresh[e];
-      codes[e] = (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : (c == -1 ? -1 : 2)));  // others never count
-    }
-    if (m) {
-      HIP_TRY(hipMemcpy(s->ei.p, edge_i, m * 4, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(s->ej.p, edge_j, m * 4, hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(s->ec.p, codes.data(), m, hipMemcpyHostToDevice));
-    }
-    if (s->precision == TOPOLOW_PRECISION_F64) {
-      s->et.alloc(m * 8);
-      if (m) HIP_TRY(hipMemcpy(s->et.p, edge_dist, m * 8, hipMemcpyHostToDevice));
-    } else {
-      std::vector<float> t(m);
-      for (size_t e = 0; e < m; ++e) t[e] = (float)edge_dist[e];
-      s->et.alloc(m * 4);
-      if (m) HIP_TRY(hipMemcpy(s->et.p, t.data(), m * 4, hipMemcpyHostToDevice));
-    }
     long long blocks = (n_edges + (long long)kThreads * 8 - 1) / ((long long)kThreads * 8);
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
@@ -791,25 +890,33 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
     s->part_sum.alloc(std::max(s->n_parts, s->dense_blocks));
     s->part_cnt.alloc(std::max(s->n_parts, s->dense_blocks));
     // Can the MAE be reduced from the encoded block instead of gathering the edge list?  Only if
-    // the list is exactly the set of measured cells the dense pass would visit.
+    // the list is exactly the set of measured cells the dense pass would visit -- checked with an
+    // order-independent fingerprint BEFORE anything is uploaded: when it holds (it does for
+    // everything the R driver builds), the list itself never travels to the device.
     s->dense_mae = false;
     s->dense_parity = !(s->row_begin == 0 && s->row_end == s->n);
+    const int* inv = s->inv.empty() ? nullptr : s->inv.data();
     const char* force = getenv("TOPOLOW_EDGE_MAE");
-    if (s->gplus.p && !(force && atoi(force) != 0)) {
-      unsigned long long fp = 0;
-      bool owned = true;
-      for (size_t e = 0; e < m && owned; ++e) {
-        const int a = edge_i[e], b = edge_j[e];
-        if (a < 0 || b < 0 || a >= s->n || b >= s->n || a == b) { owned = false; break; }
-        const int lo = a < b ? a : b, hi = a < b ? b : a;
-        int owner = lo;
-        if (s->dense_parity && (((lo + hi) & 1) != 0)) owner = hi;
-        if (owner < s->row_begin || owner >= s->row_end) { owned = false; break; }
-        const uint32_t w = encode_target(edge_dist[e], edge_thresh[e]);
-        if (w == kInfWord) { owned = false; break; }
-        fp += cell_fingerprint(lo, hi, w);
-      }
-      if (owned) {
+    if (s->gplus.p && !(force && atoi(force) != 0) && s->precision == TOPOLOW_PRECISION_F32) {
+      std::atomic<bool> owned{true};
+      std::atomic<unsigned long long> fp_total{0};
+      host_parallel(m, [&](size_t lo_e, size_t hi_e) {
+        unsigned long long fp = 0;
+        for (size_t e = lo_e; e < hi_e; ++e) {
+          int a = edge_i[e], b = edge_j[e];
+          if (a < 0 || b < 0 || a >= s->n || b >= s->n || a == b) { owned.store(false); return; }
+          if (inv) { a = inv[a]; b = inv[b]; }
+          const int lo = a < b ? a : b, hi = a < b ? b : a;
+          int owner = lo;
+          if (s->dense_parity && (((lo + hi) & 1) != 0)) owner = hi;
+          if (owner < s->row_begin || owner >= s->row_end) { owned.store(false); return; }
+          const uint32_t w = encode_target(edge_dist[e], edge_thresh[e]);
+          if (w == kInfWord) { owned.store(false); return; }
+          fp += cell_fingerprint(lo, hi, w);
+        }
+        fp_total.fetch_add(fp);
+      });
+      if (owned.load()) {
         DevBuf<unsigned long long> d_fp;
         d_fp.alloc(2);
         // on the session's stream: it is non-blocking, a null-stream memset is not ordered with it
@@ -821,10 +928,44 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
         HIP_TRY(hipStreamSynchronize(s->stream));
         unsigned long long h[2];
         HIP_TRY(hipMemcpy(h, d_fp.p, 16, hipMemcpyDeviceToHost));
-        // parity (f64) sessions keep the exact f64 edge targets
-        s->dense_mae = (h[0] == fp) && (h[1] == (unsigned long long)m) &&
-                       s->precision == TOPOLOW_PRECISION_F32;
+        s->dense_mae = (h[0] == fp_total.load()) && (h[1] == (unsigned long long)m);
       }
+    }
+    if (s->dense_mae) {   // the gather fallback is not needed: keep 1-element placeholders
+      s->ei.alloc(1); s->ej.alloc(1); s->ec.alloc(1); s->et.alloc(8);
+      return;
+    }
+    // edge-list MAE (parity sessions keep the exact f64 targets): upload the list in session labels
+    s->ei.alloc(m); s->ej.alloc(m); s->ec.alloc(m);
+    std::vector<int8_t> codes(m);
+    std::vector<int> li, lj;
+    if (inv) { li.resize(m); lj.resize(m); }
+    host_parallel(m, [&](size_t lo_e, size_t hi_e) {
+      for (size_t e = lo_e; e < hi_e; ++e) {
+        const int c = edge_thresh[e];
+        codes[e] = (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : (c == -1 ? -1 : 2)));  // others never count
+        if (inv) {
+          const int a = edge_i[e], b = edge_j[e];
+          li[e] = (a >= 0 && a < s->n) ? inv[a] : a;
+          lj[e] = (b >= 0 && b < s->n) ? inv[b] : b;
+        }
+      }
+    });
+    if (m) {
+      HIP_TRY(hipMemcpy(s->ei.p, inv ? li.data() : edge_i, m * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->ej.p, inv ? lj.data() : edge_j, m * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->ec.p, codes.data(), m, hipMemcpyHostToDevice));
+    }
+    if (s->precision == TOPOLOW_PRECISION_F64) {
+      s->et.alloc(m * 8);
+      if (m) HIP_TRY(hipMemcpy(s->et.p, edge_dist, m * 8, hipMemcpyHostToDevice));
+    } else {
+      std::vector<float> t(m);
+      host_parallel(m, [&](size_t lo_e, size_t hi_e) {
+        for (size_t e = lo_e; e < hi_e; ++e) t[e] = (float)edge_dist[e];
+      });
+      s->et.alloc(m * 4);
+      if (m) HIP_TRY(hipMemcpy(s->et.p, t.data(), m * 4, hipMemcpyHostToDevice));
     }
   });
 }
@@ -919,12 +1060,7 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
       if (s->schedule == TOPOLOW_SCHEDULE_GS) {
         TL_DISPATCH_DIM(s->dim, launch_tilegs_iteration, s, s->pos[s->cur].p, iter, s->k_host);
       } else {
-        int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_for_k(s->k_host);
-        {   // EXPERIMENT: TOPOLOW_SLAB_EARLY="<iterations>:<stages>" -- more stages while the layout unfolds
-          static const int early_iters = [] { const char* e = getenv("TOPOLOW_SLAB_EARLY"); return e ? atoi(e) : 0; }();
-          static const int early_stages = [] { const char* e = getenv("TOPOLOW_SLAB_EARLY"); const char* c = e ? strchr(e, ':') : nullptr; return c ? atoi(c + 1) : 0; }();
-          if (iter < early_iters && early_stages > stages) stages = early_stages;
-        }
+        const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_at(iter, s->k_host);
         const SlabGeom g = slab_geom(s->n, stages);
         for (int slot = 0; slot < g.n_stages; ++slot) {
           const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
@@ -1117,9 +1253,44 @@ int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_
     if (stage < 0 || stage >= g.n_stages)
       throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "stage index out of range"};
     const SlabRanges rg = slab_ranges(g, s->seed, iter, stage);
-    TL_DISPATCH_DIM(s->dim, launch_stage, s, d_pos_in, d_pos_out, (RunState*)nullptr, rg,
+    // inside a run (topolow_session_begin) the launch honours the run's stop flag and reports
+    // non-finite results through its state, like the session's own loop
+    TL_DISPATCH_DIM(s->dim, launch_stage, s, d_pos_in, d_pos_out, s->began ? s->state.p : (RunState*)nullptr, rg,
                     iter + 1, k);
+    s->iters_enqueued = std::max(s->iters_enqueued, iter + 1);
   });
+}
+
+int topolow_session_check_partial(topolow_session* s, const void* d_pos, double* d_out2, char* errbuf,
+                                  size_t errlen) {
+  if (!s || !d_pos || !d_out2 || !s->part_sum.p || !s->began) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    TL_DISPATCH_DIM(s->dim, launch_edge_error, s, d_pos, s->state.p);
+    hipLaunchKernelGGL(reduce_total_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
+                       error_parts(s), d_out2, s->state.p);
+    HIP_TRY(hipGetLastError());
+  });
+}
+
+int topolow_session_controller_step(topolow_session* s, const double* d_total2, const void* d_pos,
+                                    int32_t iter1, double k_after, char* errbuf, size_t errlen) {
+  if (!s || !d_total2 || !d_pos || !s->began) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    launch_controller(s, d_pos, iter1, k_after, nullptr, nullptr, 0, d_total2);
+    s->iters_enqueued = std::max(s->iters_enqueued, (int)iter1);
+  });
+}
+
+int topolow_session_first_nonfinite(topolow_session* s, int32_t* iteration) {
+  if (!s || !iteration) return TOPOLOW_ERR_BAD_ARGUMENT;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  RunState st;
+  if (hipMemcpy(&st, s->state.p, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return TOPOLOW_ERR_HIP;
+  *iteration = st.first_nonfinite == 0x7fffffff ? 0 : st.first_nonfinite;
+  return TOPOLOW_OK;
 }
 
 int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* sum,
@@ -1299,11 +1470,254 @@ int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
     dp.alloc(rowmajor.size());
     dout.alloc((size_t)n * n);
     HIP_TRY(hipMemcpy(dp.p, rowmajor.data(), rowmajor.size() * 8, hipMemcpyHostToDevice));
-    dim3 grid((n + kThreads - 1) / kThreads, n);
+    dim3 grid(n, (n + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(pdist_kernel, grid, dim3(kThreads), 0, 0, dp.p, n, ndim, dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(est_distances, dout.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
   });
+}
+
+// ---- ONE embedding row-sharded over several sessions (one process, one host thread per block) ----
+int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, const double* initial_positions,
+                                 int32_t n_iter, double k0, double cooling_rate, double c_repulsion,
+                                 double relative_epsilon, int32_t convergence_window,
+                                 int32_t convergence_check_freq, uint64_t seed, int32_t slab_stages,
+                                 int32_t (*interrupt_cb)(void*), void* interrupt_user, int32_t profile,
+                                 double* positions_out, int32_t* converged, int32_t* iterations,
+                                 double* final_mae, double* final_k, topolow_shard_stats* stats, char* errbuf,
+                                 size_t errlen) {
+  if (!sessions || count < 1 || !initial_positions) return TOPOLOW_ERR_BAD_ARGUMENT;
+  int rc_extra = TOPOLOW_OK;
+  const int rc = guarded(errbuf, errlen, [&] {
+    ShardedRun R;
+    R.P = count;
+    R.ss.assign(sessions, sessions + count);
+    const int n = R.ss[0]->n;
+    int expect = 0;
+    for (topolow_session* s : R.ss) {
+      if (!s || s->n != n || s->dim != R.ss[0]->dim || s->precision != R.ss[0]->precision ||
+          s->row_begin != expect || s->schedule != TOPOLOW_SCHEDULE_SLAB)
+        throw HipError{TOPOLOW_ERR_BAD_ARGUMENT,
+                       "row-sharded run: the sessions must be slab-schedule row blocks that tile [0, n) in order"};
+      expect = s->row_end;
+    }
+    if (expect != n) throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "row-sharded run: the row blocks do not cover all n rows"};
+    sharded_wire(R.ss);
+    for (topolow_session* s : R.ss) {
+      int rcb = topolow_session_set_stream(s, nullptr, 0);
+      if (rcb == TOPOLOW_OK) rcb = topolow_session_set_positions(s, initial_positions, errbuf, errlen);
+      if (rcb == TOPOLOW_OK)
+        rcb = topolow_session_begin(s, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon, convergence_window,
+                                    convergence_check_freq, seed, slab_stages, errbuf, errlen);
+      if (rcb != TOPOLOW_OK) throw HipError{rcb, errbuf ? errbuf : "session setup failed"};
+      s->profiling = false;
+    }
+    R.n_iter = n_iter;
+    R.check_freq = convergence_check_freq < 1 ? 10 : convergence_check_freq;
+    R.k0 = k0;
+    R.cooling = cooling_rate;
+    R.fixed_stages = slab_stages;
+    R.interrupt_cb = interrupt_cb;
+    R.interrupt_user = interrupt_user;
+    R.flag[0].store(0);
+    R.flag[1].store(0);
+    ShardedAbortableBarrier bar(count);
+    R.bar = &bar;
+    R.ev.resize(count);
+    for (auto& e : R.ev) e = {nullptr, nullptr};
+    auto cleanup = [&] {
+      for (int b = 0; b < count; ++b) {
+        (void)hipSetDevice(R.ss[b]->device);
+        (void)hipStreamSynchronize(R.ss[b]->stream);
+        for (hipEvent_t e : R.ev[b]) if (e) (void)hipEventDestroy(e);
+      }
+    };
+    try {
+      for (int b = 0; b < count; ++b) {
+        HIP_TRY(hipSetDevice(R.ss[b]->device));
+        for (int q = 0; q < 2; ++q) HIP_TRY(hipEventCreateWithFlags(&R.ev[b][q], hipEventDisableTiming));
+      }
+      if (profile) R.ss[0]->profiling = true;   // block 0's kernels are bracketed by timing events
+      const long long launches0 = R.ss[0]->stage_launches;
+      const double t0 = now_s();
+      auto body = [&](int r) {
+        try {
+          sharded_worker(R, r);
+        } catch (const HipError& e) {
+          std::lock_guard<std::mutex> lock(R.err_mu);
+          if (R.first_error.code == TOPOLOW_OK) R.first_error = e;
+          bar.fail();
+        } catch (const std::exception& e) {
+          std::lock_guard<std::mutex> lock(R.err_mu);
+          if (R.first_error.code == TOPOLOW_OK) R.first_error = HipError{TOPOLOW_ERR_HIP, e.what()};
+          bar.fail();
+        }
+      };
+      std::vector<std::thread> pool;
+      for (int r = 1; r < count; ++r) pool.emplace_back(body, r);
+      body(0);   // the calling thread is block 0's thread (the interrupt callback runs here)
+      for (auto& t : pool) t.join();
+      if (R.first_error.code != TOPOLOW_OK) throw R.first_error;
+      const double wall = now_s() - t0;
+      // result: every block holds the same controller state and the same best snapshot
+      topolow_session* s0 = R.ss[0];
+      HIP_TRY(hipSetDevice(s0->device));
+      RunState st;
+      HIP_TRY(hipMemcpy(&st, s0->state.p, sizeof st, hipMemcpyDeviceToHost));
+      int first_bad = 0x7fffffff;
+      for (topolow_session* s : R.ss) {
+        HIP_TRY(hipSetDevice(s->device));
+        RunState sb;
+        HIP_TRY(hipMemcpy(&sb, s->state.p, sizeof sb, hipMemcpyDeviceToHost));
+        first_bad = std::min(first_bad, sb.first_nonfinite);
+      }
+      HIP_TRY(hipSetDevice(s0->device));
+      const int ran = st.stopped ? st.iter_base : R.iters_enqueued;
+      if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->blocks = count;
+        stats->iterations_run = ran;
+        stats->n_checks = st.n_checks;
+        stats->loop_seconds = wall;
+        stats->stage_launches = s0->stage_launches - launches0;
+        stats->exchanges = R.exchanges;
+        if (profile) {
+          double sm = 0, cm = 0;
+          int64_t sl = 0, cl = 0;
+          (void)topolow_session_profile(s0, &sm, &sl, &cm, &cl, nullptr, 0);
+          stats->stage_kernel_seconds = sm * 1e-3;
+          stats->check_kernel_seconds = cm * 1e-3;
+        }
+      }
+      s0->profiling = false;
+      if (R.interrupted) {
+        set_err(errbuf, errlen, "interrupted by the caller");
+        rc_extra = TOPOLOW_ERR_INTERRUPTED;
+      } else if (first_bad != 0x7fffffff && ((first_bad + 9) / 10) * 10 <= ran &&
+                 !(st.stopped && ((first_bad + 9) / 10) * 10 == ran)) {   // reference :359-361
+        set_err(errbuf, errlen, "Numerical instability at iteration %d. Reduce k0 or c_repulsion.",
+                ((first_bad + 9) / 10) * 10);
+        rc_extra = TOPOLOW_ERR_NONFINITE;
+      } else {
+        if (positions_out) download_positions(s0, s0->best.p, positions_out);
+        if (converged) *converged = st.converged;
+        if (iterations) *iterations = st.ctl.best_iter;
+        if (final_mae) *final_mae = st.ctl.best_mae;
+        if (final_k) *final_k = st.ctl.best_k;
+      }
+    } catch (...) {
+      cleanup();
+      throw;
+    }
+    cleanup();
+  });
+  return rc != TOPOLOW_OK ? rc : rc_extra;
+}
+
+int32_t topolow_shard_rows(int32_t n, int32_t blocks, int32_t block, int32_t* row_begin, int32_t* row_end) {
+  if (n < 1 || blocks < 1) return 0;
+  int per = (n + blocks - 1) / blocks;
+  per = (per + 7) & ~7;                       // whole workgroups of 8 rows
+  const int used = (n + per - 1) / per;       // blocks that hold at least one row
+  if (block >= 0 && block < used) {
+    if (row_begin) *row_begin = block * per;
+    if (row_end) *row_end = std::min(n, (block + 1) * per);
+  } else {
+    if (row_begin) *row_begin = n;
+    if (row_end) *row_end = n;
+  }
+  return used;
+}
+
+int topolow_optimize_layout_exact_sharded(
+    const double* initial_positions, int32_t n, int32_t ndim, const double* dissimilarity_matrix,
+    const int32_t* threshold_matrix, const int32_t* degrees, const int32_t* edge_i, const int32_t* edge_j,
+    const double* edge_dist, const int32_t* edge_thresh, int64_t n_edges, int32_t n_iter, double k0,
+    double cooling_rate, double c_repulsion, double relative_epsilon, int32_t convergence_window,
+    int32_t convergence_check_freq, int32_t verbose, const topolow_options* opt_in, double* positions_out,
+    int32_t* converged, int32_t* iterations, double* final_mae, double* final_k, topolow_shard_stats* stats,
+    char* errbuf, size_t errlen) {
+  if (n < 2) {  // reference :131
+    set_err(errbuf, errlen, "Need at least 2 points for embedding");
+    return TOPOLOW_ERR_TOO_FEW_POINTS;
+  }
+  if (!initial_positions || !degrees || !positions_out || !converged || !iterations || !final_mae || !final_k ||
+      ((dissimilarity_matrix == nullptr) != (threshold_matrix == nullptr)) || n_edges < 0 ||
+      (n_edges > 0 && (!edge_i || !edge_j || !edge_dist || !edge_thresh))) {
+    set_err(errbuf, errlen, "null argument");
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  }
+  topolow_options opt;
+  if (opt_in) opt = *opt_in; else topolow_default_options(&opt);
+  if (opt.schedule == TOPOLOW_SCHEDULE_GS) {
+    set_err(errbuf, errlen, "the row-sharded path runs the slab schedule; exact Gauss-Seidel is a one-GPU schedule");
+    return TOPOLOW_ERR_UNSUPPORTED;
+  }
+  const int want = opt.n_devices > 0 ? opt.n_devices : 1;
+  const int blocks = topolow_shard_rows(n, want, -1, nullptr, nullptr);
+  const int precision = opt.precision == TOPOLOW_PRECISION_F64 ? TOPOLOW_PRECISION_F64 : TOPOLOW_PRECISION_F32;
+  const double t_start = now_s();
+  std::vector<topolow_session*> ss(blocks, nullptr);
+  int rc = TOPOLOW_OK;
+  for (int b = 0; b < blocks && rc == TOPOLOW_OK; ++b) {
+    int rb = 0, re = 0;
+    topolow_shard_rows(n, want, b, &rb, &re);
+    const int dev = opt.devices ? opt.devices[b % want] : (opt.n_devices > 1 ? b : opt.device);
+    rc = topolow_session_create(&ss[b], n, ndim, rb, re, precision, dev, errbuf, errlen);
+    if (rc) break;
+    if (!opt.keep_labels) {   // every block draws the same permutation (same n, same seed)
+      rc = topolow_session_set_relabel(ss[b], mix64(opt.seed ^ 0x1abe15eedull) | 1ull, errbuf, errlen);
+      if (rc) break;
+    }
+    if (dissimilarity_matrix)
+      rc = topolow_session_load_dense(ss[b], dissimilarity_matrix, threshold_matrix, degrees, errbuf, errlen);
+    else
+      rc = topolow_session_load_coo(ss[b], edge_i, edge_j, edge_dist, edge_thresh, n_edges, degrees, errbuf, errlen);
+    if (rc) break;
+    // this block's share of the convergence MAE: pair {lo, hi} belongs to the owner of lo when lo + hi
+    // is even, of hi when it is odd (every block then reduces about half of its row block's pairs)
+    try {
+      std::vector<int32_t> bi, bj, bt;
+      std::vector<double> bd;
+      const int* inv = ss[b]->inv.empty() ? nullptr : ss[b]->inv.data();   // ownership is by session label
+      for (int64_t e = 0; e < n_edges; ++e) {
+        const int a = edge_i[e], c = edge_j[e];
+        if (a < 0 || c < 0 || a >= n || c >= n) continue;
+        const int sa = inv ? inv[a] : a, sc = inv ? inv[c] : c;
+        const int lo = sa < sc ? sa : sc, hi = sa < sc ? sc : sa;
+        const int owner = blocks == 1 ? lo : ((((lo + hi) & 1) == 0) ? lo : hi);
+        if (owner >= rb && owner < re) { bi.push_back(a); bj.push_back(c); bd.push_back(edge_dist[e]); bt.push_back(edge_thresh[e]); }
+      }
+      rc = topolow_session_set_edges(ss[b], bi.data(), bj.data(), bd.data(), bt.data(), (int64_t)bi.size(), errbuf, errlen);
+    } catch (const std::bad_alloc&) {
+      set_err(errbuf, errlen, "out of host memory");
+      rc = TOPOLOW_ERR_HIP;
+    }
+  }
+  if (rc == TOPOLOW_OK) {
+    if (verbose) {
+      char what[64];
+      snprintf(what, sizeof what, "row-owner slabs, %d row blocks", blocks);
+      emit_header(opt, what, n, k0, cooling_rate, c_repulsion);
+    }
+    rc = topolow_sessions_run_sharded(ss.data(), blocks, initial_positions, n_iter, k0, cooling_rate, c_repulsion,
+                                      relative_epsilon, convergence_window, convergence_check_freq, opt.seed,
+                                      opt.slab_stages, opt.interrupt_cb, opt.interrupt_user, stats != nullptr,
+                                      positions_out, converged, iterations, final_mae, final_k, stats, errbuf, errlen);
+    if (rc == TOPOLOW_OK && verbose) {
+      int nc = 0;
+      if (topolow_session_check_trace(ss[0], nullptr, 0, &nc) == TOPOLOW_OK && nc > 0) {
+        std::vector<double> trace(3 * (size_t)nc);
+        if (topolow_session_check_trace(ss[0], trace.data(), nc, &nc) == TOPOLOW_OK)
+          emit_checks(opt, trace.data(), 0, nc, n_iter);
+      }
+      if (*converged)
+        emit_converged(opt, ss[0]->mailbox->ctl.plateau >= ss[0]->mailbox->ctl.window, *iterations, *final_mae);
+    }
+  }
+  for (topolow_session* s : ss) topolow_session_destroy(s);
+  if (rc == TOPOLOW_OK && stats) stats->total_seconds = now_s() - t_start;
+  return rc;
 }
 
 // ---- the .Call payload -------------------------------------------------------------------
@@ -1330,6 +1744,25 @@ int topolow_optimize_layout_exact(
   topolow_options opt;
   if (opt_in) opt = *opt_in; else topolow_default_options(&opt);
   const double t_start = now_s();
+  if (opt.n_devices > 1 || opt.devices != nullptr) {   // ONE embedding over several GPUs / row blocks
+    topolow_shard_stats sh;
+    const int rcs = topolow_optimize_layout_exact_sharded(
+        initial_positions, n, ndim, dissimilarity_matrix, threshold_matrix, degrees, edge_i, edge_j, edge_dist,
+        edge_thresh, n_edges, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon, convergence_window,
+        convergence_check_freq, verbose, &opt, positions_out, converged, iterations, final_mae, final_k,
+        stats ? &sh : nullptr, errbuf, errlen);
+    if (rcs == TOPOLOW_OK && stats) {
+      std::memset(stats, 0, sizeof *stats);
+      stats->schedule_used = TOPOLOW_SCHEDULE_SLAB;
+      stats->precision_used = opt.precision == TOPOLOW_PRECISION_F64 ? TOPOLOW_PRECISION_F64 : TOPOLOW_PRECISION_F32;
+      stats->iterations_run = sh.iterations_run;
+      stats->n_checks = sh.n_checks;
+      stats->device_seconds = sh.loop_seconds;
+      stats->total_seconds = sh.total_seconds;
+      stats->stage_launches = sh.stage_launches;
+    }
+    return rcs;
+  }
 
   int schedule = opt.schedule;
   const int gs_max_n = opt.gs_max_n > 0 ? opt.gs_max_n : kDefaultGsMaxN;
@@ -1395,15 +1828,37 @@ int topolow_optimize_layout_exact(
   if (rc != TOPOLOW_OK) return rc;
   double t_dev0 = 0.0, t_dev1 = 0.0;
   int iters_run = 0, stopped = 0;
+  double t_setup = 0.0;
   do {
     if (tile_gs) {
       rc = topolow_session_set_schedule(s, TOPOLOW_SCHEDULE_GS);
       if (rc) break;
     }
-    rc = topolow_session_load_dense(s, dissimilarity_matrix, threshold_matrix, degrees, errbuf, errlen);
-    if (rc) break;
-    rc = topolow_session_set_edges(s, edge_i, edge_j, edge_dist, edge_thresh, n_edges, errbuf, errlen);
-    if (rc) break;
+    if (!opt.keep_labels) {   // slabs / tiles of random points instead of index-contiguous ones
+      rc = topolow_session_set_relabel(s, mix64(opt.seed ^ 0x1abe15eedull) | 1ull, errbuf, errlen);
+      if (rc) break;
+    }
+    // The 16 arguments carry the matrix twice: dense (800 + 400 MB at config 3) and as the list of its
+    // measured upper-triangle cells (R/core.R:383-402 and :429-436 build both from one matrix).  When
+    // the list is verified to BE the matrix, the encoded block is built from the list -- a quarter of
+    // the bytes over PCIe -- and the dense arrays are only read on the host, once, to verify it.
+    bool from_edges = false;
+    if (precision == TOPOLOW_PRECISION_F32 && getenv("TOPOLOW_DENSE_UPLOAD") == nullptr &&
+        edges_are_the_matrix(dissimilarity_matrix, threshold_matrix, n, edge_i, edge_j, edge_dist, edge_thresh, n_edges)) {
+      rc = topolow_session_load_coo(s, edge_i, edge_j, edge_dist, edge_thresh, n_edges, degrees, errbuf, errlen);
+      if (rc) break;
+      rc = topolow_session_set_edges(s, edge_i, edge_j, edge_dist, edge_thresh, n_edges, errbuf, errlen);
+      if (rc) break;
+      // the device-side fingerprint (count and hash of the block's measured cells == the list) rules
+      // out what the host pass cannot see cheaply: a pair listed twice
+      from_edges = topolow_session_uses_dense_mae(s) != 0;
+    }
+    if (!from_edges) {
+      rc = topolow_session_load_dense(s, dissimilarity_matrix, threshold_matrix, degrees, errbuf, errlen);
+      if (rc) break;
+      rc = topolow_session_set_edges(s, edge_i, edge_j, edge_dist, edge_thresh, n_edges, errbuf, errlen);
+      if (rc) break;
+    }
     rc = topolow_session_set_positions(s, initial_positions, errbuf, errlen);
     if (rc) break;
     rc = topolow_session_begin(s, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon,
@@ -1411,6 +1866,7 @@ int topolow_optimize_layout_exact(
                                opt.slab_stages, errbuf, errlen);
     if (rc) break;
     t_dev0 = now_s();
+    t_setup = t_dev0 - t_start;
     if (verbose)
       emit_header(opt, tile_gs ? "tile Gauss-Seidel" : "row-owner slabs", n, k0, cooling_rate, c_repulsion);
     int reported = 0;
@@ -1451,6 +1907,7 @@ int topolow_optimize_layout_exact(
     stats->iterations_run = iters_run;
     stats->n_checks = s->mailbox->n_checks;
     stats->device_seconds = t_dev1 - t_dev0;
+    stats->setup_seconds = t_setup;
     stats->stage_launches = s->stage_launches;
   }
   if (rc == TOPOLOW_OK && verbose && *converged)

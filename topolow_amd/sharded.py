@@ -41,7 +41,11 @@ def dist_info():
 
 
 def row_block(n: int, world: int, rank: int):
+    """Rows [b, e) of rank `rank`: contiguous blocks of `per` rows, per a multiple of 8 (whole stage-kernel
+    workgroups; the same rule as the library's topolow_shard_rows).  Trailing ranks of a small problem get an
+    empty block (b == e == n); relax_sharded refuses to run with one."""
     per = -(-n // world)
+    per = (per + 7) & ~7
     b = min(n, rank * per)
     e = min(n, b + per)
     return b, e, per
@@ -87,34 +91,43 @@ class Collectives:
         else:
             self.dist.all_gather_into_tensor(out, mine.clone() if self.backend == "gloo" else mine)
 
-    def all_reduce_sum(self, values: List[float]) -> List[float]:
+    def all_reduce_tensor(self, t):
+        """In-place sum of a small tensor over the ranks; enqueued on the tensor's stream (RCCL), no host
+        synchronisation."""
         if self.world == 1:
-            return values
-        import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor(values, dtype=torch.float64, device=dev)
-        self.dist.all_reduce(t)
-        return t.cpu().tolist()
+            return
+        if t.is_cuda and self.backend == "gloo":
+            host = t.cpu()
+            self.dist.all_reduce(host)
+            t.copy_(host)
+        else:
+            self.dist.all_reduce(t)
 
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
 
-    def max_float(self, v: float) -> float:
-        if self.world == 1:
-            return v
+    def _host_reduce(self, v: float, op):
         import torch
         dev = "cuda" if self.backend == "nccl" else "cpu"
         t = torch.tensor([v], dtype=torch.float64, device=dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=op)
         return float(t.item())
+
+    def max_float(self, v: float) -> float:
+        return v if self.world == 1 else self._host_reduce(v, self.dist.ReduceOp.MAX)
+
+    def min_float(self, v: float) -> float:
+        return v if self.world == 1 else self._host_reduce(v, self.dist.ReduceOp.MIN)
 
 
 # --------------------------------------------------------------------------------------
 # row-sharded relaxation
 # --------------------------------------------------------------------------------------
 class HipBackend:
-    """Row block of one embedding on this rank's GPU (libtopolow_relax.so session)."""
+    """Row block of one embedding on this rank's GPU (libtopolow_relax.so session).  Stage kernels,
+    the error pass, the controller and its snapshot all run on the device, on the stream the
+    collectives use: the loop never waits for the GPU except where `poll` is called."""
 
     def __init__(self, n, ndim, row_begin, row_end, device):
         import torch
@@ -138,23 +151,36 @@ class HipBackend:
         t[: self.n] = self.torch.from_numpy(np.ascontiguousarray(pos_np, dtype=np.float32)).to(self.device)
         return t
 
-    def to_host(self, t):
-        return t[: self.n].double().cpu().numpy()
-
-    def begin(self, n_iter, k0, cool, c_rep, seed):
-        self.session.begin(n_iter, k0, cool, c_rep, 1e-4, 1 << 30, 1 << 30, seed, 0)
+    def begin(self, pos0, n_iter, k0, cool, c_rep, eps, window, freq, seed):
+        # the session's own buffers take the start positions too: its best snapshot starts from them
+        self.session.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+        self.session.set_positions(pos0)
+        self.session.begin(n_iter, k0, cool, c_rep, eps, window, freq, seed, 0)
+        self._t2 = self.torch.zeros(2, dtype=self.torch.float64, device=self.device)
 
     def stage(self, pos_in, pos_out, it, slot, stages, k):
         self.session.stage(pos_in.data_ptr(), pos_out.data_ptr(), it, slot, stages, k)
 
+    def check_partial(self, pos):
+        self.session.check_partial(pos.data_ptr(), self._t2.data_ptr())
+        return self._t2
+
+    def controller_step(self, total2, pos, iter1, k_after):
+        self.session.controller_step(total2.data_ptr(), pos.data_ptr(), iter1, k_after)
+
+    def poll(self):
+        """(stopped, iterations_run) after waiting for everything enqueued."""
+        iters_run, stopped, _mae = self.session.sync()
+        return bool(stopped), int(iters_run)
+
+    def first_nonfinite(self):
+        return self.session.first_nonfinite()
+
+    def finish(self):
+        return self.session.finish()
+
     def edge_error(self, pos):
         return self.session.edge_error(pos.data_ptr())
-
-    def all_finite(self, pos):
-        return bool(self.torch.isfinite(pos[: self.n]).all().item())
-
-    def clone(self, pos):
-        return pos.clone()
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
@@ -164,25 +190,32 @@ def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, ini
                   n_iter: int, k0: float, cooling_rate: float, c_repulsion: float,
                   relative_epsilon: float = 1e-4, convergence_window: int = 5,
                   convergence_check_freq: int = 3, seed: int = 0, slab_stages: int = 0,
-                  timers: bool = False) -> ShardedResult:
-    """The slab relaxation of one embedding over `world` ranks.  Mirrors the single-GPU session
-    loop (topolow_relax.hip: topolow_session_enqueue) and the reference's iteration structure
-    (src/optimization.cpp:193-374 of the reference)."""
-    _, _, per = row_block(n, world, rank)
+                  timers: bool = False, sync_every: int = 8) -> ShardedResult:
+    """The slab relaxation of one embedding over `world` processes (one per GPU).  Mirrors the
+    single-GPU session loop (topolow_relax.hip: topolow_session_enqueue) and the reference's iteration
+    structure (src/optimization.cpp:193-374 of the reference).
+
+    Per stage: one kernel launch + one all-gather of the position slices; per check: the block's error
+    pass, an all-reduce of two doubles and the controller kernel -- all enqueued, nothing read back.  The
+    controller is replicated (identical inputs, identical decisions), so the ranks learn of a stop by
+    reading their own state: every `sync_every`-th check each rank waits for its stream and looks; they all
+    see the same state at the same point of the schedule, so they leave the loop together.  Work enqueued
+    after the stop is a no-op on the device (kernels test the stop flag)."""
+    b, e, per = row_block(n, world, rank)
+    if e <= b:
+        raise ValueError(f"row-sharded run: rank {rank} of {world} would own no rows of {n} points "
+                         f"(blocks are whole 8-row workgroups); use at most {-(-n // 8)} ranks")
     rows_total = per * world
     pos = [backend.to_device(initial_positions, rows_total), backend.new_positions(rows_total)]
     cur = 0
-    best = backend.clone(pos[0])
-    backend.begin(n_iter, k0, cooling_rate, c_repulsion, seed)
     freq = convergence_check_freq if convergence_check_freq >= 1 else 10
+    backend.begin(initial_positions, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon,
+                  convergence_window, freq, seed)
     k = k0
-    maes, iters, ks = [], [], []
-    converged = False
-    best_state = dict(best_mae=float(np.finfo(np.float64).max), best_k=k0, best_iter=0)
     t_stage = t_gather = t_check = 0.0
-    iters_run = 0
+    checks = 0
     for it in range(n_iter):
-        stages = slab_stages if slab_stages > 0 else _native.slab_stages_for_k(k)
+        stages = slab_stages if slab_stages > 0 else _native.slab_stages_at(it, k)
         n_slots = len(_native.slab_plan(n, stages, seed, it))
         for slot in range(n_slots):
             if timers:   # breakdown pass: host-synchronised, so slower than the timed pass
@@ -199,30 +232,28 @@ def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, ini
                 backend.stage(pos[cur], pos[cur ^ 1], it, slot, stages, k)
                 coll.all_gather_rows(pos[cur ^ 1], per, rank)
             cur ^= 1
-        iters_run = it + 1
         k *= (1.0 - cooling_rate)
         if (it + 1) % freq == 0 or it == n_iter - 1:
             t0 = time.perf_counter() if timers else 0.0
-            s, c = backend.edge_error(pos[cur])
-            s, c = coll.all_reduce_sum([s, float(c)])
-            err = s / c if c > 0 else 0.0
-            maes.append(err); iters.append(it + 1); ks.append(k)
-            r = _native.controller_script(maes, iters, ks, k0, convergence_window, relative_epsilon)
-            if r["snapshots"][len(maes) - 1]:
-                best = backend.clone(pos[cur])
-            best_state = r
+            total = backend.check_partial(pos[cur])
+            coll.all_reduce_tensor(total)
+            backend.controller_step(total, pos[cur], it + 1, k)
+            checks += 1
             if timers:
+                backend.synchronize()
                 t_check += time.perf_counter() - t0
-            if r["stopped_at"] >= 0:
-                converged = True
+            if checks % max(1, sync_every) == 0 and backend.poll()[0]:
                 break
-        if (it + 1) % 10 == 0 and not backend.all_finite(pos[cur]):
+    _stopped, iters_run = backend.poll()
+    bad = int(coll.min_float(float(backend.first_nonfinite() or 0x7FFFFFFF)))
+    if bad != 0x7FFFFFFF:
+        t = -(-bad // 10) * 10                      # reference :359-361: inspected every 10th iteration,
+        if t <= iters_run and not (_stopped and t == iters_run):    # after that iteration's check
             raise _native.NativeError(
-                _native.ERR_NONFINITE,
-                "Numerical instability at iteration %d. Reduce k0 or c_repulsion." % (it + 1))
-    return ShardedResult(backend.to_host(best), converged, best_state["best_iter"],
-                         best_state["best_mae"], best_state["best_k"], iters_run, len(maes),
-                         t_stage, t_gather, t_check)
+                _native.ERR_NONFINITE, "Numerical instability at iteration %d. Reduce k0 or c_repulsion." % t)
+    r = backend.finish()
+    return ShardedResult(r.positions, bool(r.converged), int(r.iterations), float(r.final_mae), float(r.final_k),
+                         iters_run, int(r.info.get("n_checks", checks)), t_stage, t_gather, t_check)
 
 
 # --------------------------------------------------------------------------------------
@@ -254,7 +285,7 @@ def encode_words_torch(torch, t, code=None):
 
 
 def load_synthetic_block(backend: HipBackend, n: int, latent_dim: int, missing: float, seed: int,
-                         rank: int, world: int):
+                         rank: int, world: int, rows=None):
     """Fills this rank's encoded row block of a synthetic problem (same recipe as
     synthetic.make_problem, but the missing mask and the noise come from a symmetric hash of
     the pair so every rank can build its rows independently).  Returns the rank's share of
@@ -265,7 +296,7 @@ def load_synthetic_block(backend: HipBackend, n: int, latent_dim: int, missing: 
     dev = backend.device
     rng = np.random.Generator(np.random.PCG64(seed))
     x = torch.from_numpy(synthetic.latent_points(n, latent_dim, rng)).to(dev)
-    b, e, _ = row_block(n, world, rank)
+    b, e = rows if rows is not None else row_block(n, world, rank)[:2]
     ld = s.encoded_ld
     rows = e - b
     # view the session's HBM block as a torch tensor
