@@ -35,8 +35,13 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--min-timed", dest="min_timed", type=float, default=0.25,
+                    help="repeat the K-step timed pass until this many seconds have been timed (N = 1)")
+    ap.add_argument("--devices", type=str, default="",
+                    help="--mode sharded in ONE process: comma-separated HIP ordinals of the row blocks, e.g. "
+                         "0,1,2,3,4,5,6,7 (an ordinal may repeat: several row blocks on one GPU)")
     ap.add_argument("--points", dest="n", type=int, default=0, help="override the number of points (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -52,7 +57,7 @@ def workload_single(n):
     t0 = time.time()
     prob = synthetic.make_problem(n, latent_dim=5, missing=0.7, seed=12345)
     init = synthetic.initial_positions(prob.dissimilarity, 5, 12345)
-    call = core.prepare_layout_call(prob.dissimilarity, 5, 1, 5.0, 0.01, 0.01, 1e-4, 5, init, False, 3,
+    call = core.prepare_layout_call(prob.dissimilarity, 5, 1000, 5.0, 0.01, 0.01, 1e-4, 5, init, False, 3,
                                     True)
     return call, time.time() - t0
 
@@ -69,7 +74,8 @@ def run_single(args):
 
     t0 = time.time()
     s = _native.Session(n, ndim, precision="f32")
-    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_relabel(2024)          # random labels, as the one-shot entry uses them
+    s.load_coo(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.degrees)
     s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
     upload_s = time.time() - t0
 
@@ -79,25 +85,33 @@ def run_single(args):
         # the window is large enough that it never stops the run
         s.begin(total, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 2024, args.stages)
 
-    # ---- timed pass (no profiling events) ----
-    fresh(W + K)
-    done = 0
-    while done < W:
-        done += s.enqueue(W - done)
-    s.sync()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    done = 0
-    while done < K:
-        got = s.enqueue(K - done)
-        if got == 0:
-            break
-        done += got
-    iters_run, stopped, last_mae = s.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert done == K and not stopped, (done, stopped)
+    def timed_pass():
+        """W untimed iterations, then EXACTLY K timed ones between two device synchronisations."""
+        fresh(W + K)
+        done = 0
+        while done < W:
+            done += s.enqueue(W - done)
+        s.sync()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        done = 0
+        while done < K:
+            got = s.enqueue(K - done)
+            if got == 0:
+                break
+            done += got
+        _iters, stopped, _mae = s.sync()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t
+        assert done == K and not stopped, (done, stopped)
+        return el
+
+    # ---- timed passes (no profiling events): repeated until >= 0.25 s have been timed ----
+    passes = []
+    while (sum(passes) < args.min_timed or len(passes) < 3) and len(passes) < 200:
+        passes.append(timed_pass())
     res = s.finish()
+    elapsed = float(np.median(passes))
 
     # ---- profiled pass: HIP events around every stage launch on the session stream ----
     fresh(W + K)
@@ -113,18 +127,25 @@ def run_single(args):
     s.set_profiling(False)
     s.sync()
 
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC run of this same
-    # command (profiles/: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, per launch); null if absent.
-    traffic = None
-    try:
-        if n != 10000:
-            raise ValueError("the committed PMC run is for the config-3 size only")
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
-            for name, vals in json.load(fh).items():
-                if "slab_stage_" in name and "<5, float" in name and "hbm_traffic_bytes_per_launch" in vals:
-                    traffic = vals["hbm_traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the figure is
+    # the committed rocprofv3 PMC run of this same command (profiles/, FETCH_SIZE x2 on gfx950 +
+    # WRITE_SIZE, per launch); null when the workload is not the profiled one.
+    traffic, traffic_src = None, None
+    for prof in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        try:
+            if n != 10000:
+                break
+            with open(os.path.join(ROOT, "profiles", prof)) as fh:
+                for name, vals in json.load(fh).items():
+                    if "slab_stage_" in name and "<5, float" in name and "hbm_traffic_bytes_per_launch" in vals:
+                        traffic = vals["hbm_traffic_bytes_per_launch"]
+                        traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                       "FETCH_SIZE x2 on gfx950; measured by the commit that added the file, not "
+                                       "in this run)" % prof)
+            if traffic is not None:
+                break
+        except Exception:
+            continue
 
     bytes_iter = s.bytes_per_iteration
     stages_per_iter = stage_launches / K
@@ -149,20 +170,48 @@ def run_single(args):
                                "c_repulsion=0.01, check every 3 iterations",
                    "n_points": n, "ndim": ndim, "schedule": "slab", "stages_per_iteration": stages_per_iter,
                    "edges": int(call.edge_i.size), "mae_pass": "dense" if s.uses_dense_mae else "edges"},
+        "timing": {"passes": len(passes), "timed_seconds": float(sum(passes)),
+                   "iterations_per_s": {"min": K / max(passes), "median": K / elapsed, "max": K / min(passes)},
+                   "note": "value = K / median pass; every pass is W untimed + exactly K timed iterations "
+                           "from the same start, bracketed by device synchronisations"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                       "separate passes, FETCH_SIZE x2 on gfx950)" if traffic else None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "slab_stage_pipe_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
-                     "timing": "HIP events on the session stream around every stage launch, in a second "
-                               "pass of the same K iterations (inside the timed pass the events themselves "
-                               "cost ~19% throughput); rocprofv3 kernel-trace mean: profiles/r01_kernel_stats.csv",
+                     "timing": "HIP events on the session stream around every stage launch, in a separate "
+                               "pass of the same K iterations (inside the timed passes the events themselves "
+                               "would cost throughput); rocprofv3 kernel-trace mean: profiles/",
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "check_us": (check_ms * 1e3 / checks) if checks else None},
         "final_mae": res.final_mae,
         "final_mae_iteration": res.iterations,
         "setup_seconds": {"generate": gen_s, "upload_encode": upload_s},
     }
+
+    # ---- whole run to the controller's own stop (early 16-stage iterations and all checks included) ----
+    s.set_positions(call.initial_positions)
+    s.begin(1000, k0, cool, c_rep, 1e-4, 5, 3, 2024, args.stages)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    s.run()
+    iters_run, _st, _m = s.sync()
+    torch.cuda.synchronize()
+    whole = time.perf_counter() - t
+    q = s.finish()
+    out["whole_run"] = {"iterations_run": int(iters_run), "seconds": whole, "iterations_per_s": iters_run / whole,
+                        "converged": bool(q.converged), "best_iteration": int(q.iterations), "final_mae": q.final_mae}
+    # parity gate of the benched schedule at full size: the oracle's config-3 records (reference order, f64,
+    # ~46 CPU-minutes each; tests/golden/cfg3_oracle_seed*.json).  One run against mean_ref: the device's own
+    # run-to-run sd at this size is 1.1 % (32 seeds, tests/study), so a single run is held to 4 %; the MEAN is
+    # held to the contract band by tests/test_gpu_contract.py.
+    if n == 10000:
+        import glob
+        recs = [json.load(open(f)) for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden",
+                                                                             "cfg3_oracle_seed[0-9]*.json")))]
+        ref = float(np.mean([r["final_mae"] for r in recs]))
+        out["mae_check"] = {"gpu_slab_final_mae": q.final_mae, "cpu_oracle_final_mae_mean": ref,
+                            "oracle_records": len(recs), "relative_difference": q.final_mae / ref - 1.0,
+                            "band": 0.04}
+        assert q.converged and abs(q.final_mae / ref - 1.0) <= 0.04, out["mae_check"]
 
     if not args.no_cpu_baseline:
         from oracle import topolow_oracle as orc
@@ -177,15 +226,21 @@ def run_single(args):
                                         call.edge_dist, call.edge_thresh, ci, k0, cool, c_rep, 1e-4, 10 ** 9,
                                         ci, seed=2024)
         cpu_s = time.perf_counter() - t0
-        # same number of iterations on the GPU for the MAE comparison
+        # the same number of iterations on the GPU: the device's reported MAE must be the oracle's edge MAE of
+        # the device's positions (exact arithmetic check), and the two schedules must be at the same error
+        # level (3 iterations into the unfolding phase single runs differ by up to +-10 %: band 25 %)
         fresh(ci)
         s.begin(ci, k0, cool, c_rep, 1e-4, 10 ** 9, ci, 2024, args.stages)
         s.run()
         g = s.finish()
+        sm, cnt = orc.edge_error(g.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
         out["cpu_baseline"] = {"value": ci / cpu_s, "unit": "iterations/s", "cores": 1, "kind": "port",
                                "sample": f"{ci} iterations of the same N={n} workload (shuffled "
                                          "Gauss-Seidel oracle, f64, g++ -O2), incl. its final MAE check"}
-        out["mae_check"] = {"iterations": ci, "gpu_slab": g.final_mae, "cpu_oracle": ref.final_mae}
+        out["mae_check_early"] = {"iterations": ci, "gpu_slab": g.final_mae, "cpu_oracle": ref.final_mae,
+                                  "oracle_mae_of_gpu_positions": sm / cnt}
+        assert abs(g.final_mae - sm / cnt) <= 2e-5 * (sm / cnt), out["mae_check_early"]
+        assert abs(g.final_mae / ref.final_mae - 1.0) <= 0.25, out["mae_check_early"]
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     s.close()
     print(json.dumps(out))

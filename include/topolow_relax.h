@@ -334,14 +334,20 @@ int topolow_session_edge_error(topolow_session* s, const void* d_pos, double* su
  * same seed: positions bit for bit, the MAE to rounding (its partial sums are grouped by block).
  * ------------------------------------------------------------------------------------- */
 typedef struct topolow_shard_stats {
-  int32_t blocks, iterations_run, n_checks, reserved0;
+  int32_t blocks, iterations_run, n_checks;
+  int32_t groups;                /* host threads / streams: blocks that share a GPU share one */
   double loop_seconds;           /* host wall time of the relaxation loop, all blocks */
   double total_seconds;          /* including session creation, upload, encode, download */
-  double stage_kernel_seconds;   /* block 0: summed durations of its stage kernels (HIP events) */
-  double check_kernel_seconds;   /* block 0: error pass + partial exchange + controller */
+  double stage_kernel_seconds;   /* first GPU: summed durations of its blocks' stage kernels (HIP events) */
+  double check_kernel_seconds;   /* first GPU: error passes + partial exchange + controllers */
   int64_t stage_launches;        /* block 0 */
-  int64_t exchanges;             /* cross-block barriers */
-  int64_t reserved[4];
+  int64_t exchanges;             /* stage and check boundaries (an event barrier when groups > 1) */
+  /* Measurement aid, IN and out (topolow_sessions_run_sharded only): when > 0 on entry, the GPUs are
+   * drained once these iterations have run and `timed_seconds` covers the rest of the loop -- the
+   * steady state without the 16-stage iterations of the unfolding phase. */
+  int32_t warmup_iterations, reserved1;
+  double timed_seconds;
+  int64_t reserved[2];
 } topolow_shard_stats;
 
 /* Row block `block` of `blocks` over n rows: contiguous, whole 8-row workgroups; returns how many

@@ -53,9 +53,8 @@ def test_config2_h3n2_gs_equals_oracle_replay(ndim):
     assert got.converged == ref.converged and got.iterations == ref.iterations
     assert np.abs(got.positions - ref.positions).max() <= 1e-10
     assert got.final_mae == pytest.approx(ref.final_mae, rel=1e-10)
-    # the reference-order (std::shuffle) oracle lands at the same error level
-    shuf = [orc.optimize_layout_exact(*layout_call_args(call), seed=s).final_mae for s in range(5)]
-    assert abs(got.final_mae - np.mean(shuf)) <= max(4 * np.std(shuf), 0.05 * np.mean(shuf))
+    # (the statistics against the reference-order oracle -- 20 seeds, contract band -- are in
+    #  tests/test_gpu_contract.py::test_exact_gauss_seidel_in_tournament_order_meets_the_contract)
 
 
 def test_config2_slab_schedule_on_h3n2_when_forced():
@@ -63,11 +62,13 @@ def test_config2_slab_schedule_on_h3n2_when_forced():
     m = h3n2_matrix()
     call = core.prepare_layout_call(m, 5, 1000, H3N2["k0"], H3N2["cooling_rate"], H3N2["c_repulsion"],
                                     1e-4, 5, None, False, 3, False, np.random.default_rng(7))
-    gs = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=s, schedule="gs").final_mae
-          for s in range(6)]
+    from tests import parity_problems as pp
+    ref = pp.oracle_distribution("h3n2_ndim5")      # same problem definition (tests/parity_problems.py: h3n2_call)
     slab = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=s, schedule="slab").final_mae
-            for s in range(6)]
-    assert abs(np.mean(slab) - np.mean(gs)) <= max(4 * np.std(gs), 0.08 * np.mean(gs))
+            for s in range(20)]
+    # 285 points in slabs of 72 columns, 9 % measured: not the regime the slab schedule is built for (AUTO takes
+    # the exact kernel here); stated band 5 % of the oracle mean
+    assert abs(np.mean(slab) - ref["mean_final_mae"]) <= 0.05 * ref["mean_final_mae"], (np.mean(slab), ref["mean_final_mae"])
 
 
 def test_config5_batched_cv_matches_published_holdout_mae():

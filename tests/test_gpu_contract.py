@@ -1,0 +1,147 @@
+"""The statistical parity contract, run with -m gpu.
+
+The reference's pair order comes from std::shuffle seeded by std::random_device
+(src/optimization.cpp:153-154,196): it is not reproducible even from itself, and its own test accepts
+relative 1e-2 between two runs of a 3-point problem (tests/testthat/test-deprecated.R:65-67).  A device
+schedule is therefore accepted on DISTRIBUTIONS:
+
+    | mean_device(final MAE) - mean_ref |  <=  max(3 sd_ref, 1 % of mean_ref)
+
+with mean_ref / sd_ref from >= 20 oracle seeds (reference order, f64) committed under
+tests/golden/oracle_dist_<problem>.json (tests/golden/make_oracle_distributions.py), and for BASELINE
+config 3 at full size from the oracle's full-size records (tests/golden/cfg3_oracle_seed*.json, ~46 CPU
+minutes each).  Further bands, stated where they are asserted:
+  * stop iteration: mean within max(3 sd_ref, 10 %) of the oracle's;
+  * every single run within 12 % of the oracle mean (a run that falls into a side minimum: the largest
+    deviation seen in the 32-seed studies is 8.3 %);
+  * recovered distances: a run's distances among the first 48 points differ from the oracle's seed-mean
+    by no more than 1.5 x the largest gap an oracle seed shows + 0.5 %.
+Measured means behind these tests: tests/study/gpu_relabel_study.py, DESIGN.md section 2.
+"""
+import numpy as np
+import pytest
+
+from oracle import topolow_oracle as orc
+from tests import parity_problems as pp
+from tests.conftest import layout_call_args
+from topolow_amd import _native
+
+pytestmark = pytest.mark.gpu
+SEEDS = 20
+
+
+def head_dist(p, k):
+    p = np.asarray(p)[:k]
+    return np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))[np.triu_indices(k, 1)]
+
+
+def contract_band(ref):
+    return max(3.0 * ref["sd_final_mae"], 0.01 * ref["mean_final_mae"])
+
+
+def check_runs(name, runs, mean_band=None, schedule=None):
+    ref = pp.oracle_distribution(name)
+    assert ref["n_seeds"] >= 20
+    m = ref["mean_final_mae"]
+    got = np.array([r.final_mae for r in runs])
+    its = np.array([r.iterations for r in runs])
+    band = contract_band(ref) if mean_band is None else mean_band
+    assert abs(got.mean() - m) <= band, (name, schedule, got.mean(), m, band)
+    assert np.all(np.abs(got - m) <= 0.12 * m), (name, schedule, got.min(), got.max(), m)
+    assert abs(its.mean() - ref["mean_iterations"]) <= max(3.0 * ref["sd_iterations"], 0.10 * ref["mean_iterations"])
+    assert all(r.converged for r in runs) == all(x["converged"] for x in ref["runs"])
+    mean_head = np.array(ref["head_dist_mean"])
+    worst_ref = max(ref["head_gap"])
+    gaps = [float(np.mean(np.abs(head_dist(r.positions, ref["head_points"]) - mean_head) / mean_head)) for r in runs]
+    assert np.mean(gaps) <= 1.5 * worst_ref + 0.005, (name, schedule, np.mean(gaps), worst_ref)
+    return got
+
+
+@pytest.mark.parametrize("name", ["syn1500_h3n2params", "cfg3gen_1500", "cfg3gen_2048", "cfg3b_1500"])
+def test_slab_schedule_meets_the_contract(name):
+    """The fast path (AUTO above 1024 points): row-owner slabs, fp32, random labels."""
+    call, _ = pp.build(name)
+    runs = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s) for s in range(SEEDS)]
+    assert all(r.info["schedule"] == "slab" and r.info["precision"] == "f32" for r in runs)
+    check_runs(name, runs, schedule="slab")
+    # the MAE the device controller reports is the reference's edge MAE of the returned positions
+    r = runs[0]
+    sm, cnt = orc.edge_error(r.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert r.final_mae == pytest.approx(sm / cnt, rel=2e-5)
+
+
+@pytest.mark.parametrize("name", ["h3n2_ndim5", "h3n2_ndim4", "syn1500_h3n2params", "cfg3gen_1500"])
+def test_exact_gauss_seidel_in_tournament_order_meets_the_contract(name):
+    """schedule = "gs" (AUTO up to 1024 points): the reference's algorithm, f64, pairs visited in
+    round-robin tournament order instead of std::shuffle order."""
+    call, _ = pp.build(name)
+    runs = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s, schedule="gs")
+            for s in range(SEEDS)]
+    assert all(r.info["schedule"] == "gs" and r.info["precision"] == "f64" for r in runs)
+    check_runs(name, runs, schedule="gs")
+
+
+def test_tournament_order_at_2048_points_stated_band():
+    """At N = 2048 the oracle's own spread is 0.55 %, the contract band 1.65 %.  The tournament order (every
+    point updated exactly once per round) lands +1.8 % above the shuffled order there (20 seeds, SE 0.6 %):
+    inside the band within its error bar, not safely.  Stated band for schedule = "gs" at this size: 3 %."""
+    name = "cfg3gen_2048"
+    call, _ = pp.build(name)
+    runs = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s, schedule="gs", precision="f32")
+            for s in range(SEEDS)]
+    check_runs(name, runs, mean_band=0.03 * pp.oracle_distribution(name)["mean_final_mae"], schedule="gs")
+
+
+def test_config3_full_size_meets_the_contract():
+    """BASELINE config 3 (N = 10 000, 70 % missing, ndim 5) run to the controller's own stop, against the
+    oracle's full-size records.  12 slab seeds; the exact tile Gauss-Seidel schedule (1.5 s per run) with 3."""
+    recs = pp.cfg3_oracle_records()
+    assert len(recs) >= 2 and all(r["n"] == 10000 and r["converged"] for r in recs)
+    ref_mae = np.array([r["final_mae"] for r in recs])
+    ref_it = np.array([r["iterations"] for r in recs])
+    m = ref_mae.mean()
+    sd = ref_mae.std(ddof=1)
+    band = max(3.0 * sd, 0.01 * m)
+    call, _ = pp.cfg3_generator(10000)
+    ref_d = [head_dist(np.array(r["positions_head"]), 48) for r in recs]
+    mean_d = np.mean(ref_d, axis=0)
+    worst_ref = max(float(np.mean(np.abs(d - mean_d) / mean_d)) for d in ref_d)
+    slab = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s) for s in range(12)]
+    got = np.array([r.final_mae for r in slab])
+    assert all(r.converged and r.info["schedule"] == "slab" for r in slab)
+    assert abs(got.mean() - m) <= band, (got.mean(), m, band)
+    assert np.all(np.abs(got - m) <= 0.06 * m), (got.min(), got.max())
+    its = np.array([r.iterations for r in slab])
+    assert abs(its.mean() - ref_it.mean()) <= max(3.0 * ref_it.std(ddof=1), 0.10 * ref_it.mean())
+    gaps = [float(np.mean(np.abs(head_dist(r.positions, 48) - mean_d) / mean_d)) for r in slab]
+    assert np.mean(gaps) <= max(1.5 * worst_ref + 0.005, 0.03), (np.mean(gaps), worst_ref)
+    sm, cnt = orc.edge_error(slab[0].positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert slab[0].final_mae == pytest.approx(sm / cnt, rel=2e-5)
+    # exact Gauss-Seidel across workgroups (tile tournament order, random labels): stated band 3 %
+    # (6 seeds: -0.2 % +- 1.4 %; three runs cannot resolve 1 %)
+    gs = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s, schedule="gs", precision="f32")
+          for s in range(3)]
+    assert all(r.converged and r.info["schedule"] == "gs" for r in gs)
+    assert abs(np.mean([r.final_mae for r in gs]) - m) <= 0.03 * m
+
+
+def test_small_epsilon_controller_parity():
+    """relative_epsilon as the reference's own callers pass it: 1e-6 (Euclidify's final embedding,
+    R/core.R:1263) and 1e-10 (inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:905).  The fp32 slab path
+    forms its convergence MAE from fp32 positions; the question is whether the controller -- which carries
+    the reference's f64 epsilon semantics -- stops where the f64 computation stops.
+      (a) same schedule, same seeds, fp32 against f64 sessions: stop iteration and converged flag;
+      (b) fp32 slab against the oracle's distribution at that epsilon (contract band)."""
+    for name in ("cfg3gen_1500_eps1e-6", "cfg3gen_1500_eps1e-10"):
+        call, _ = pp.build(name)
+        ref = pp.oracle_distribution(name)
+        f32 = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s) for s in range(SEEDS)]
+        f64 = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s, precision="f64",
+                                                    schedule="slab") for s in range(8)]
+        assert all(r.info["precision"] == "f32" for r in f32) and all(r.info["precision"] == "f64" for r in f64)
+        for a, b in zip(f32, f64):
+            assert a.converged == b.converged
+            assert abs(a.iterations - b.iterations) <= 6, (name, a.iterations, b.iterations)   # two checks
+            assert a.final_mae == pytest.approx(b.final_mae, rel=2e-4)
+        check_runs(name, f32, schedule="slab")
+        assert abs(np.mean([r.iterations for r in f32]) - ref["mean_iterations"]) <= 3 * ref["sd_iterations"] + 6

@@ -24,8 +24,11 @@ def _same(a, b):
     assert a.final_mae == pytest.approx(b.final_mae, rel=1e-6)
 
 
-@pytest.mark.parametrize("thr", [0.0, 0.15])
-def test_row_blocks_on_one_device_equal_the_single_session(thr):
+@pytest.mark.parametrize("thr,thread_per_block", [(0.0, "0"), (0.15, "0"), (0.15, "1")])
+def test_row_blocks_on_one_device_equal_the_single_session(thr, thread_per_block, monkeypatch):
+    """thread_per_block = "1": every block gets its own host thread and stream and the blocks meet at the HIP-event
+    barrier -- the path GPUs of one node take -- instead of sharing their GPU's stream."""
+    monkeypatch.setenv("TOPOLOW_SHARD_THREAD_PER_BLOCK", thread_per_block)
     call, _ = pp.random_problem(1203, 5, 0.7, seed=31, thresholds=thr, n_iter=400, k0=8.0, cool=0.03, c_rep=0.01)
     one = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=5, schedule="slab")
     assert one.converged and one.info["schedule"] == "slab"
@@ -40,6 +43,7 @@ def test_row_blocks_on_one_device_equal_the_single_session(thr):
         call.convergence_check_freq, devices=[0, 0, 0, 0], seed=5)
     _same(coo, one)
     assert coo.info["blocks"] == 4 and coo.info["exchanges"] > coo.info["iterations_run"]
+    assert coo.info["groups"] == (4 if thread_per_block == "1" else 1)
     sm, cnt = orc.edge_error(coo.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
     assert coo.final_mae == pytest.approx(sm / cnt, rel=2e-5)
 
@@ -117,6 +121,16 @@ def test_config4_size_two_blocks_equal_one_block_and_host_overhead():
     assert r1.final_mae == pytest.approx(r2.final_mae, rel=1e-6)
     # one block: everything the loop does besides block 0's kernels is host / barrier overhead
     busy = p1.info["stage_kernel_seconds"] + p1.info["check_kernel_seconds"]
+    print("config 4, one block : loop %.2f ms, block-0 kernels %.2f ms" % (1e3 * r1.info["loop_seconds"], 1e3 * busy))
+    print("config 4, two blocks: loop %.2f ms, %d exchanges" % (1e3 * r2.info["loop_seconds"], r2.info["exchanges"]))
+    assert p1.info["stage_kernel_seconds"] > 0 and p1.info["check_kernel_seconds"] > 0
     assert r1.info["loop_seconds"] <= 1.10 * busy, (r1.info, p1.info)
-    # two blocks share the GPU: their kernels overlap, so the loop must not take longer than one block's
-    assert r2.info["loop_seconds"] <= 1.10 * r1.info["loop_seconds"], (r1.info, r2.info)
+    # two blocks on the one GPU share its stream (stream order is their barrier).  The same pairs in twice as many
+    # launches: each half-size grid pays its own fill and drain (3 125 workgroups = 2.4 rounds of the chip's 1 280
+    # resident ones, against 4.9 rounds for the whole grid), so the GPU time grows (measured 1.2 x); what the HOST
+    # adds is the loop's wall time beyond the summed durations of all kernels on that stream:
+    busy2 = p2.info["stage_kernel_seconds"] + p2.info["check_kernel_seconds"]
+    print("config 4, two blocks: kernels %.2f ms" % (1e3 * busy2))
+    assert r2.info["groups"] == 1
+    assert r2.info["loop_seconds"] <= 1.10 * busy2, (r2.info, p2.info)
+    assert r2.info["loop_seconds"] <= 1.35 * r1.info["loop_seconds"], (r1.info, r2.info)

@@ -55,9 +55,10 @@ class TopolowRunStats(C.Structure):
 
 class TopolowShardStats(C.Structure):
     _fields_ = [("blocks", C.c_int32), ("iterations_run", C.c_int32), ("n_checks", C.c_int32),
-                ("reserved0", C.c_int32), ("loop_seconds", C.c_double), ("total_seconds", C.c_double),
+                ("groups", C.c_int32), ("loop_seconds", C.c_double), ("total_seconds", C.c_double),
                 ("stage_kernel_seconds", C.c_double), ("check_kernel_seconds", C.c_double),
-                ("stage_launches", C.c_int64), ("exchanges", C.c_int64), ("reserved", C.c_int64 * 4)]
+                ("stage_launches", C.c_int64), ("exchanges", C.c_int64), ("warmup_iterations", C.c_int32),
+                ("reserved1", C.c_int32), ("timed_seconds", C.c_double), ("reserved", C.c_int64 * 2)]
 
 
 class TopolowProblem(C.Structure):
@@ -516,8 +517,8 @@ def optimize_layout_exact_sharded(initial_positions, degrees, edge_i, edge_j, ed
         int(bool(verbose)), C.byref(opt), _dp(out), C.byref(conv), C.byref(iters), C.byref(fmae), C.byref(fk),
         C.byref(stats), err, len(err))
     _check(rc, err)
-    info = dict(schedule="slab", blocks=stats.blocks, iterations_run=stats.iterations_run, n_checks=stats.n_checks,
-                loop_seconds=stats.loop_seconds, total_seconds=stats.total_seconds,
+    info = dict(schedule="slab", blocks=stats.blocks, groups=stats.groups, iterations_run=stats.iterations_run,
+                n_checks=stats.n_checks, loop_seconds=stats.loop_seconds, total_seconds=stats.total_seconds,
                 stage_kernel_seconds=stats.stage_kernel_seconds, check_kernel_seconds=stats.check_kernel_seconds,
                 stage_launches=stats.stage_launches, exchanges=stats.exchanges, seed=int(opt.seed))
     return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value), float(fmae.value),
@@ -526,7 +527,7 @@ def optimize_layout_exact_sharded(initial_positions, degrees, edge_i, edge_j, ed
 
 def run_sharded(sessions, initial_positions, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon=1e-4,
                 convergence_window=5, convergence_check_freq=3, seed=0, slab_stages=0, interrupt=None,
-                profile=False) -> NativeResult:
+                profile=False, warmup_iterations=0) -> NativeResult:
     """ONE embedding over the given row-block sessions (topolow_sessions_run_sharded): one process, one
     host thread per block, peer-stored position slices, replicated controller."""
     lib = load()
@@ -537,6 +538,7 @@ def run_sharded(sessions, initial_positions, n_iter, k0, cooling_rate, c_repulsi
     conv, iters = C.c_int32(0), C.c_int32(0)
     fmae, fk = C.c_double(0.0), C.c_double(0.0)
     stats = TopolowShardStats()
+    stats.warmup_iterations = int(warmup_iterations)   # measurement aid: timed_seconds starts after these
     err = C.create_string_buffer(512)
     cb = INTERRUPT_CB(lambda _u: 1 if interrupt() else 0) if interrupt is not None else INTERRUPT_CB()
     rc = lib.topolow_sessions_run_sharded(hs, len(sessions), _dp(pos0), int(n_iter), float(k0), float(cooling_rate),
@@ -545,10 +547,10 @@ def run_sharded(sessions, initial_positions, n_iter, k0, cooling_rate, c_repulsi
                                           int(slab_stages), cb, None, int(bool(profile)), _dp(out), C.byref(conv),
                                           C.byref(iters), C.byref(fmae), C.byref(fk), C.byref(stats), err, len(err))
     _check(rc, err)
-    info = dict(schedule="slab", blocks=stats.blocks, iterations_run=stats.iterations_run, n_checks=stats.n_checks,
-                loop_seconds=stats.loop_seconds, stage_kernel_seconds=stats.stage_kernel_seconds,
+    info = dict(schedule="slab", blocks=stats.blocks, groups=stats.groups, iterations_run=stats.iterations_run,
+                n_checks=stats.n_checks, loop_seconds=stats.loop_seconds, stage_kernel_seconds=stats.stage_kernel_seconds,
                 check_kernel_seconds=stats.check_kernel_seconds, stage_launches=stats.stage_launches,
-                exchanges=stats.exchanges)
+                exchanges=stats.exchanges, timed_seconds=stats.timed_seconds)
     return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value), float(fmae.value),
                         float(fk.value), info)
 

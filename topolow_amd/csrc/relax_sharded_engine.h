@@ -10,18 +10,23 @@
 //     same epilogue, into the next-position buffer of every other block (peer stores -- over xGMI when
 //     the blocks sit on different GPUs): the all-gather of the position slices is fused into the
 //     kernel, there is no separate collective and no staging copy;
-//   * a cross-block barrier out of HIP events: every block records an event behind its stage kernel
-//     and makes its stream wait for the events of the others.  Peer-written data is consumed only by
+//   * a barrier between the GPUs out of HIP events: every GPU's thread records an event behind its
+//     stage kernels and makes its stream wait for the events of the others (blocks that share a GPU share
+//     a stream: stream order is their barrier).  Peer-written data is consumed only by
 //     kernels that START after that wait -- kernel-boundary visibility, the guarantee HIP gives for
 //     ordinary (coarse-grained) device memory; nothing spins inside a kernel on a remote flag.
 // Per convergence check each block reduces its parity share of the measured pairs, folds the
 // partials into one (sum, count) and peer-stores it into a slot of every block's rank table; after
 // one more barrier every block runs the SAME controller on the SAME numbers in the same order, so
 // the decisions (stop / snapshot) are replicated without any host round trip.
-// One host thread per block enqueues that block's work (the event waits are per pair of blocks, a
-// single thread would issue P^2 of them per stage); threads meet in a spin barrier between "record"
-// and "wait" so an event is always recorded before anyone waits on it.  The calling thread is block
-// 0's thread: only it polls the caller's interrupt callback (R's API is main-thread only).
+// One host thread per GPU enqueues that GPU's work (the event waits are per pair of GPUs, a single
+// thread would issue G^2 of them per stage); threads meet in a spin barrier between "record" and
+// "wait" so an event is always recorded before anyone waits on it.  The calling thread is the first
+// GPU's thread: only it polls the caller's interrupt callback (R's API is main-thread only).
+// Measured on one MI355X (tests/study/shard_exchange_latency.py): with every block forced into its own
+// thread and stream the barrier costs 27 / 62 / 198 us per stage at 2 / 4 / 8 blocks -- eight threads
+// issuing 72 event calls per stage into ONE device's runtime lock; that is why same-GPU blocks share a
+// stream, and it is the upper bound of what 8 GPUs (one lock each, 9 calls per thread) can cost.
 
 struct ShardedAbortableBarrier {
   std::atomic<int> count{0};
@@ -47,41 +52,58 @@ struct ShardedAbortableBarrier {
   void fail() { failed.store(true, std::memory_order_release); }
 };
 
+// Blocks that share a GPU form a GROUP: one host thread enqueues all of them on ONE stream, stage by
+// stage, so stream order is their barrier (their kernels each fill the chip anyway).  Groups -- i.e.
+// different GPUs, one block each in production -- meet at the event barrier.  TOPOLOW_SHARD_THREAD_PER_BLOCK=1
+// makes every block its own group (tests drive the cross-group path on one GPU with it).
+struct ShardedGroup {
+  std::vector<int> blocks;     // indices into ShardedRun::ss, ascending
+  hipStream_t stream = nullptr;
+  int device = 0;
+};
+
 struct ShardedRun {
   std::vector<topolow_session*> ss;
+  std::vector<ShardedGroup> groups;
   int P = 0;
   int n_iter = 0, check_freq = 3;
   double k0 = 0, cooling = 0;
   int fixed_stages = 0;
-  std::vector<std::array<hipEvent_t, 2>> ev;
+  std::vector<std::array<hipEvent_t, 2>> ev;      // per group
   ShardedAbortableBarrier* bar = nullptr;
-  std::atomic<int> flag[2];      // published by block 0's thread before barrier g (slot g & 1): bit 0 stop, bit 1 interrupt
+  std::atomic<int> flag[2];      // published by group 0's thread before barrier g (slot g & 1): bit 0 stop, bit 1 interrupt
   int32_t (*interrupt_cb)(void*) = nullptr;
   void* interrupt_user = nullptr;
   std::mutex err_mu;
   HipError first_error{TOPOLOW_OK, ""};
+  int warmup_iters = 0;          // > 0: the clock of `timed_seconds` starts when these iterations have drained
+  double t_timed0 = 0.0;
   // results of the loop
   int iters_enqueued = 0;
   bool interrupted = false;
   long long exchanges = 0;
 };
 
-// One block's enqueue loop (thread r).  Throws HipError; the caller marks the barrier failed.
+// One group's enqueue loop (thread r).  Throws HipError; the caller marks the barrier failed.
 inline void sharded_worker(ShardedRun& R, int r) {
-  topolow_session* s = R.ss[r];
-  HIP_TRY(hipSetDevice(s->device));
+  const ShardedGroup& G = R.groups[r];
+  const int n_groups = (int)R.groups.size();
+  topolow_session* lead = R.ss[G.blocks[0]];
+  HIP_TRY(hipSetDevice(G.device));
   long long g = 0;          // exchange counter, identical in every thread
   int seen = 0;             // flag value read at the last exchange, identical in every thread
   auto exchange = [&]() -> bool {
-    HIP_TRY(hipEventRecord(R.ev[r][g & 1], s->stream));
+    int f = 0;
     if (r == 0) {
-      int f = s->mailbox->stopped ? 1 : 0;
+      f = R.ss[0]->mailbox->stopped ? 1 : 0;
       if (R.interrupted) f |= 2;
-      R.flag[g & 1].store(f, std::memory_order_release);
     }
+    if (n_groups == 1) { seen = f; ++g; return true; }   // stream order is the barrier
+    HIP_TRY(hipEventRecord(R.ev[r][g & 1], G.stream));
+    if (r == 0) R.flag[g & 1].store(f, std::memory_order_release);
     if (!R.bar->wait()) return false;
-    for (int p = 0; p < R.P; ++p)
-      if (p != r) HIP_TRY(hipStreamWaitEvent(s->stream, R.ev[p][g & 1], 0));
+    for (int p = 0; p < n_groups; ++p)
+      if (p != r) HIP_TRY(hipStreamWaitEvent(G.stream, R.ev[p][g & 1], 0));
     seen = R.flag[g & 1].load(std::memory_order_acquire);
     ++g;
     return true;
@@ -91,20 +113,30 @@ inline void sharded_worker(ShardedRun& R, int r) {
   int iter = 0;
   for (; iter < R.n_iter; ++iter) {
     if (seen != 0) break;
+    if (R.warmup_iters > 0 && iter == R.warmup_iters) {   // measurement only: drain, meet, start the clock
+      HIP_TRY(hipStreamSynchronize(G.stream));
+      if (n_groups > 1 && !R.bar->wait()) return;
+      if (r == 0) R.t_timed0 = now_s();
+      if (n_groups > 1 && !R.bar->wait()) return;
+    }
     if (r == 0 && R.interrupt_cb != nullptr && iter > 0 && iter % 50 == 0 && !R.interrupted)   // reference :364
       R.interrupted = R.interrupt_cb(R.interrupt_user) != 0;   // published at the next exchange
     const int stages = R.fixed_stages > 0 ? R.fixed_stages : slab_stages_at(iter, k);
-    const SlabGeom geo = slab_geom(s->n, stages);
+    const SlabGeom geo = slab_geom(lead->n, stages);
     for (int slot = 0; slot < geo.n_stages; ++slot) {
-      const SlabRanges rg = slab_ranges(geo, s->seed, iter, slot);
-      TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[cur].p, s->pos[cur ^ 1].p, s->state.p, rg, iter + 1, k,
-                      s->push_tab[cur ^ 1].p, s->n_push);
+      const SlabRanges rg = slab_ranges(geo, lead->seed, iter, slot);
+      for (int b : G.blocks) {
+        topolow_session* s = R.ss[b];
+        TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[cur].p, s->pos[cur ^ 1].p, s->state.p, rg, iter + 1, k,
+                        s->push_tab[cur ^ 1].p, s->n_push);
+      }
       if (!exchange()) return;
       cur ^= 1;
     }
     k *= (1.0 - R.cooling);   // reference :289
     if ((iter + 1) % R.check_freq == 0 || iter == R.n_iter - 1) {   // reference :294
-      {
+      for (int b : G.blocks) {
+        topolow_session* s = R.ss[b];
         ProfScope prof(s, &s->prof_check);
         TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[cur].p, s->state.p);
         hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
@@ -112,13 +144,16 @@ inline void sharded_worker(ShardedRun& R, int r) {
         HIP_TRY(hipGetLastError());
       }
       if (!exchange()) return;
-      ProfScope prof(s, &s->prof_check);
-      launch_controller(s, s->pos[cur].p, iter + 1, k, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
+      for (int b : G.blocks) {
+        topolow_session* s = R.ss[b];
+        ProfScope prof(s, &s->prof_check);
+        launch_controller(s, s->pos[cur].p, iter + 1, k, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
+      }
     }
   }
-  s->cur = cur;
+  for (int b : G.blocks) R.ss[b]->cur = cur;
   if (r == 0) { R.iters_enqueued = iter; R.exchanges = g; }
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipStreamSynchronize(G.stream));
 }
 
 // Wires `count` loaded sessions (row blocks tiling [0, n) in order, same n / ndim / precision) into one

@@ -1487,6 +1487,7 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
                                  double* final_mae, double* final_k, topolow_shard_stats* stats, char* errbuf,
                                  size_t errlen) {
   if (!sessions || count < 1 || !initial_positions) return TOPOLOW_ERR_BAD_ARGUMENT;
+  const int warmup_iters = stats != nullptr ? stats->warmup_iterations : 0;   // in: see the header
   int rc_extra = TOPOLOW_OK;
   const int rc = guarded(errbuf, errlen, [&] {
     ShardedRun R;
@@ -1503,7 +1504,24 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
     }
     if (expect != n) throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "row-sharded run: the row blocks do not cover all n rows"};
     sharded_wire(R.ss);
-    for (topolow_session* s : R.ss) {
+    // groups: blocks that share a GPU share one stream and one host thread
+    const char* per_block = getenv("TOPOLOW_SHARD_THREAD_PER_BLOCK");
+    const bool thread_per_block = per_block != nullptr && per_block[0] == '1';
+    for (int b = 0; b < count; ++b) {
+      int gidx = -1;
+      if (!thread_per_block)
+        for (size_t q = 0; q < R.groups.size(); ++q) if (R.groups[q].device == R.ss[b]->device) gidx = (int)q;
+      if (gidx < 0) {
+        R.groups.emplace_back();
+        gidx = (int)R.groups.size() - 1;
+        R.groups[gidx].device = R.ss[b]->device;
+        R.groups[gidx].stream = R.ss[b]->own_stream;
+      }
+      R.groups[gidx].blocks.push_back(b);
+    }
+    const int n_groups = (int)R.groups.size();
+    for (int b = 0; b < count; ++b) {
+      topolow_session* s = R.ss[b];
       int rcb = topolow_session_set_stream(s, nullptr, 0);
       if (rcb == TOPOLOW_OK) rcb = topolow_session_set_positions(s, initial_positions, errbuf, errlen);
       if (rcb == TOPOLOW_OK)
@@ -1512,6 +1530,8 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
       if (rcb != TOPOLOW_OK) throw HipError{rcb, errbuf ? errbuf : "session setup failed"};
       s->profiling = false;
     }
+    for (const ShardedGroup& G : R.groups)
+      for (int b : G.blocks) R.ss[b]->stream = G.stream;   // (idle: set_positions / begin have synchronised)
     R.n_iter = n_iter;
     R.check_freq = convergence_check_freq < 1 ? 10 : convergence_check_freq;
     R.k0 = k0;
@@ -1521,23 +1541,26 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
     R.interrupt_user = interrupt_user;
     R.flag[0].store(0);
     R.flag[1].store(0);
-    ShardedAbortableBarrier bar(count);
+    ShardedAbortableBarrier bar(n_groups);
     R.bar = &bar;
-    R.ev.resize(count);
+    R.ev.resize(n_groups);
     for (auto& e : R.ev) e = {nullptr, nullptr};
     auto cleanup = [&] {
-      for (int b = 0; b < count; ++b) {
-        (void)hipSetDevice(R.ss[b]->device);
-        (void)hipStreamSynchronize(R.ss[b]->stream);
-        for (hipEvent_t e : R.ev[b]) if (e) (void)hipEventDestroy(e);
+      for (int q = 0; q < n_groups; ++q) {
+        (void)hipSetDevice(R.groups[q].device);
+        (void)hipStreamSynchronize(R.groups[q].stream);
+        for (hipEvent_t e : R.ev[q]) if (e) (void)hipEventDestroy(e);
       }
+      for (topolow_session* s : R.ss) s->stream = s->own_stream;
     };
     try {
-      for (int b = 0; b < count; ++b) {
-        HIP_TRY(hipSetDevice(R.ss[b]->device));
-        for (int q = 0; q < 2; ++q) HIP_TRY(hipEventCreateWithFlags(&R.ev[b][q], hipEventDisableTiming));
+      for (int q = 0; q < n_groups; ++q) {
+        HIP_TRY(hipSetDevice(R.groups[q].device));
+        for (int e = 0; e < 2; ++e) HIP_TRY(hipEventCreateWithFlags(&R.ev[q][e], hipEventDisableTiming));
       }
-      if (profile) R.ss[0]->profiling = true;   // block 0's kernels are bracketed by timing events
+      R.warmup_iters = warmup_iters;
+      if (profile)   // the kernels of the first GPU's blocks are bracketed by timing events
+        for (int b : R.groups[0].blocks) R.ss[b]->profiling = true;
       const long long launches0 = R.ss[0]->stage_launches;
       const double t0 = now_s();
       auto body = [&](int r) {
@@ -1554,8 +1577,8 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
         }
       };
       std::vector<std::thread> pool;
-      for (int r = 1; r < count; ++r) pool.emplace_back(body, r);
-      body(0);   // the calling thread is block 0's thread (the interrupt callback runs here)
+      for (int r = 1; r < n_groups; ++r) pool.emplace_back(body, r);
+      body(0);   // the calling thread is the first GPU's thread (the interrupt callback runs here)
       for (auto& t : pool) t.join();
       if (R.first_error.code != TOPOLOW_OK) throw R.first_error;
       const double wall = now_s() - t0;
@@ -1576,20 +1599,25 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
       if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->blocks = count;
+        stats->groups = n_groups;
         stats->iterations_run = ran;
         stats->n_checks = st.n_checks;
         stats->loop_seconds = wall;
         stats->stage_launches = s0->stage_launches - launches0;
         stats->exchanges = R.exchanges;
+        stats->warmup_iterations = warmup_iters;
+        stats->timed_seconds = (warmup_iters > 0 && R.t_timed0 > 0.0) ? (t0 + wall) - R.t_timed0 : wall;
         if (profile) {
-          double sm = 0, cm = 0;
-          int64_t sl = 0, cl = 0;
-          (void)topolow_session_profile(s0, &sm, &sl, &cm, &cl, nullptr, 0);
-          stats->stage_kernel_seconds = sm * 1e-3;
-          stats->check_kernel_seconds = cm * 1e-3;
+          for (int b : R.groups[0].blocks) {
+            double sm = 0, cm = 0;
+            int64_t sl = 0, cl = 0;
+            (void)topolow_session_profile(R.ss[b], &sm, &sl, &cm, &cl, nullptr, 0);
+            stats->stage_kernel_seconds += sm * 1e-3;
+            stats->check_kernel_seconds += cm * 1e-3;
+          }
         }
       }
-      s0->profiling = false;
+      for (topolow_session* s : R.ss) s->profiling = false;
       if (R.interrupted) {
         set_err(errbuf, errlen, "interrupted by the caller");
         rc_extra = TOPOLOW_ERR_INTERRUPTED;
