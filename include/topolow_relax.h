@@ -191,6 +191,12 @@ int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_
  * positions n x ndim float64 column-major (host) -> est_distances n x n float64 (host). */
 int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
                           double* est_distances, int32_t device, char* errbuf, size_t errlen);
+/* Rows [row_begin, row_end) of the same matrix: out is (row_end - row_begin) x n, row-major (= rows
+ * row_begin.. of the symmetric n x n result).  For problems whose n x n float64 result should not be
+ * held at once (BASELINE config 4: 20 GB): the caller streams row blocks.  Either entry keeps device
+ * memory bounded (tiles of <= 256 MB). */
+int topolow_est_distances_rows(const double* positions, int32_t n, int32_t ndim, int32_t row_begin,
+                               int32_t row_end, double* out, int32_t device, char* errbuf, size_t errlen);
 
 /* ---------------------------------------------------------------------------------------
  * Device-resident session: the same relaxation with inputs kept in HBM, for callers that

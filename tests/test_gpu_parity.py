@@ -297,6 +297,11 @@ def test_est_distances_matches_numpy():
         est = _native.est_distances(p)
         assert np.allclose(est, numpy_pdist(p), rtol=1e-14, atol=1e-14)
         assert np.array_equal(est, est.T) and np.all(np.diag(est) == 0)
+    # row blocks of the same matrix (large problems stream them instead of holding n x n float64)
+    p = rng.normal(size=(70001, 3))
+    blk = _native.est_distances_rows(p, 69990, 70001)          # more rows than grid.y allows: rows ride in grid.x
+    want = np.sqrt(((p[69990:, None, :] - p[None, :, :]) ** 2).sum(-1))
+    assert blk.shape == (11, 70001) and np.allclose(blk, want, rtol=1e-14, atol=1e-14)
 
 
 def test_euclidean_embedding_drop_in_on_gpu(tmp_path):

@@ -180,6 +180,9 @@ def load() -> C.CDLL:
     lib.topolow_est_distances.restype = C.c_int
     lib.topolow_est_distances.argtypes = [dp, C.c_int32, C.c_int32, dp, C.c_int32, C.c_char_p,
                                           C.c_size_t]
+    lib.topolow_est_distances_rows.restype = C.c_int
+    lib.topolow_est_distances_rows.argtypes = [dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, C.c_int32,
+                                               C.c_char_p, C.c_size_t]
     vp = C.c_void_p
     lib.topolow_session_create.restype = C.c_int
     lib.topolow_session_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32,
@@ -564,6 +567,19 @@ def est_distances(positions) -> np.ndarray:
     err = C.create_string_buffer(512)
     rc = lib.topolow_est_distances(_dp(pos), n, dim, _dp(out), int(options.get("device", -1)),
                                    err, len(err))
+    _check(rc, err)
+    return out
+
+
+def est_distances_rows(positions, row_begin: int, row_end: int) -> np.ndarray:
+    """Rows [row_begin, row_end) of as.matrix(dist(positions)): shape (row_end - row_begin, n)."""
+    lib = load()
+    pos = _f64F(positions)
+    n, dim = pos.shape
+    out = np.empty((int(row_end) - int(row_begin), n), dtype=np.float64)
+    err = C.create_string_buffer(512)
+    rc = lib.topolow_est_distances_rows(_dp(pos), n, dim, int(row_begin), int(row_end), _dp(out),
+                                        int(options.get("device", -1)), err, len(err))
     _check(rc, err)
     return out
 

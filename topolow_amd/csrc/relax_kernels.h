@@ -1007,19 +1007,22 @@ __global__ __launch_bounds__(kThreads) void scatter_edges_kernel(
   if (b >= row_begin && b < row_end) out[(size_t)(b - row_begin) * ld + a] = w;
 }
 
-// est_distances = as.matrix(dist(positions)) (reference R/core.R:474), f64.
-// positions: n x dim row-major f64; out: n x n f64 (symmetric, so layout-agnostic).
+// est_distances = as.matrix(dist(positions)) (reference R/core.R:474), f64, rows [row0, row0 + rows).
+// positions: n x dim row-major f64; out: rows x n f64, row-major (the full matrix is symmetric, so
+// R's column-major reading of an n x n result is the same matrix).
 __global__ __launch_bounds__(kThreads) void pdist_kernel(const double* __restrict__ pos, int n,
-                                                         int dim, double* __restrict__ out) {
-  const int j = blockIdx.y * kThreads + threadIdx.x;   // grid: x = row, y = 256-column group
-  const int i = blockIdx.x;
-  if (j >= n) return;
+                                                         int dim, int row0, int rows,
+                                                         double* __restrict__ out) {
+  const int j = blockIdx.y * kThreads + threadIdx.x;   // grid: x = row of the block, y = 256-column group
+  const int r = blockIdx.x;
+  if (j >= n || r >= rows) return;
+  const int i = row0 + r;
   double s = 0.0;
   for (int d = 0; d < dim; ++d) {
     const double dev = pos[(size_t)i * dim + d] - pos[(size_t)j * dim + d];
     s += dev * dev;
   }
-  out[(size_t)i * n + j] = ::sqrt(s);
+  out[(size_t)r * n + j] = ::sqrt(s);
 }
 
 }  // namespace topolow

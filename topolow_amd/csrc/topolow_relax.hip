@@ -1458,9 +1458,12 @@ int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_
   }
 }
 
-int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
-                          double* est_distances, int32_t device, char* errbuf, size_t errlen) {
-  if (!positions || !est_distances || n < 1 || ndim < 1) return TOPOLOW_ERR_BAD_ARGUMENT;
+// rows [row_begin, row_end) of as.matrix(dist(positions)): out is (row_end - row_begin) x n, row-major.
+// Device memory is bounded: the rows are produced in tiles of at most 256 MB.
+int topolow_est_distances_rows(const double* positions, int32_t n, int32_t ndim, int32_t row_begin,
+                               int32_t row_end, double* out, int32_t device, char* errbuf, size_t errlen) {
+  if (!positions || !out || n < 1 || ndim < 1 || row_begin < 0 || row_end > n || row_begin > row_end)
+    return TOPOLOW_ERR_BAD_ARGUMENT;
   return guarded(errbuf, errlen, [&] {
     select_device(device);
     std::vector<double> rowmajor((size_t)n * ndim);
@@ -1468,13 +1471,22 @@ int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
       for (int d = 0; d < ndim; ++d) rowmajor[(size_t)i * ndim + d] = positions[i + (size_t)d * n];
     DevBuf<double> dp, dout;
     dp.alloc(rowmajor.size());
-    dout.alloc((size_t)n * n);
     HIP_TRY(hipMemcpy(dp.p, rowmajor.data(), rowmajor.size() * 8, hipMemcpyHostToDevice));
-    dim3 grid(n, (n + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(pdist_kernel, grid, dim3(kThreads), 0, 0, dp.p, n, ndim, dout.p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(est_distances, dout.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+    const int tile = std::max(1, std::min(row_end - row_begin, (int)((256ll << 20) / (8ll * n))));
+    dout.alloc((size_t)tile * n);
+    for (int r0 = row_begin; r0 < row_end; r0 += tile) {
+      const int rows = std::min(tile, row_end - r0);
+      dim3 grid(rows, (n + kThreads - 1) / kThreads);
+      hipLaunchKernelGGL(pdist_kernel, grid, dim3(kThreads), 0, 0, dp.p, n, ndim, r0, rows, dout.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpy(out + (size_t)(r0 - row_begin) * n, dout.p, (size_t)rows * n * 8, hipMemcpyDeviceToHost));
+    }
   });
+}
+
+int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,
+                          double* est_distances, int32_t device, char* errbuf, size_t errlen) {
+  return topolow_est_distances_rows(positions, n, ndim, 0, n, est_distances, device, errbuf, errlen);
 }
 
 // ---- ONE embedding row-sharded over several sessions (one process, one host thread per block) ----

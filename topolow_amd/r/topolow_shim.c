@@ -11,6 +11,7 @@
  *     _topolow_cv_fold                      one fold's payload from the list of non-NA cells
  *                                           (R/adaptive_sampling.R:2608-2616 + R/core.R:269-436)
  *     _topolow_est_distances                as.matrix(dist(positions))  (R/core.R:474)
+ *     _topolow_est_distances_cols           a block of its columns, for n x n results too large to hold
  *
  * No logic lives here: unmarshal, call the library, marshal, and turn error codes into R errors
  * AFTER every native resource has been released (Rf_error longjmps).
@@ -368,11 +369,31 @@ SEXP _topolow_est_distances(SEXP positionsSEXP) {
   return out;
 }
 
+/* Columns first..last (1-based, inclusive) of the same matrix: an n x (last - first + 1) block, for
+ * problems whose full n x n result should be streamed rather than held (BASELINE config 4). */
+SEXP _topolow_est_distances_cols(SEXP positionsSEXP, SEXP firstSEXP, SEXP lastSEXP) {
+  if (!Rf_isReal(positionsSEXP) || !Rf_isMatrix(positionsSEXP))
+    Rf_error("positions must be a numeric matrix");
+  const int n = Rf_nrows(positionsSEXP), ndim = Rf_ncols(positionsSEXP);
+  const int first = Rf_asInteger(firstSEXP), last = Rf_asInteger(lastSEXP);
+  if (first < 1 || last > n || first > last) Rf_error("columns out of range");
+  /* the library writes rows first..last of the symmetric matrix row-major = these columns column-major */
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, n, last - first + 1));
+  char err[512];
+  err[0] = '\0';
+  const int rc = topolow_est_distances_rows(REAL(positionsSEXP), n, ndim, first - 1, last, REAL(out),
+                                            opt_int("topolow.device", -1), err, sizeof err);
+  UNPROTECT(1);
+  if (rc != TOPOLOW_OK) Rf_error("%s", err[0] ? err : "libtopolow_relax failed");
+  return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"_topolow_optimize_layout_exact_cpp", (DL_FUNC)&_topolow_optimize_layout_exact_cpp, 16},
     {"_topolow_optimize_layout_exact_batch", (DL_FUNC)&_topolow_optimize_layout_exact_batch, 1},
     {"_topolow_cv_fold", (DL_FUNC)&_topolow_cv_fold, 8},
     {"_topolow_est_distances", (DL_FUNC)&_topolow_est_distances, 1},
+    {"_topolow_est_distances_cols", (DL_FUNC)&_topolow_est_distances_cols, 3},
     {NULL, NULL, 0}};
 
 void R_init_topolow(DllInfo* dll) {
