@@ -46,7 +46,7 @@ typedef struct topolow_options {
                            std::random_device, src/optimization.cpp:153-154) */
   int32_t schedule;     /* TOPOLOW_SCHEDULE_* */
   int32_t precision;    /* TOPOLOW_PRECISION_* */
-  int32_t slab_stages;  /* 0 = adaptive: topolow_slab_stages_at(iteration, k) */
+  int32_t slab_stages;  /* 0 = adaptive: topolow_slab_stages_at(iteration, k, ndim) */
   int32_t device;       /* HIP device ordinal; -1 = current device */
   int32_t gs_max_n;     /* AUTO switches to the slab schedule above this n; 0 = default */
   int32_t n_devices;    /* > 1 (or a non-NULL `devices`): ONE embedding row-block sharded over
@@ -236,7 +236,8 @@ int topolow_session_load_coo(topolow_session* s, const int32_t* edge_i, const in
                              int64_t n_edges, const int32_t* degrees, char* errbuf,
                              size_t errlen);
 /* Device-side fill: the caller writes the session's encoded block itself (a device buffer of
- * (row_end-row_begin) x ld uint32 words, word = topolow_encode_target(); diagonal, padding
+ * (row_end-row_begin) x ld uint32 words, row-major: the word of (row r of the block, column c) sits at
+ * topolow_encoded_index(r, c, ld) = r * ld + c; word = topolow_encode_target(); diagonal, padding
  * and unmeasured cells = topolow_encode_target(+Inf, 0)), then commits it with the degrees. */
 void* topolow_session_encoded_ptr(topolow_session* s);
 int32_t topolow_session_encoded_ld(const topolow_session* s);
@@ -397,17 +398,19 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
  * r1_end; second range empty unless the slab wraps) in execution order; returns n_stages. */
 int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t iter,
                           int32_t* ranges_out, int32_t max_stages);
-/* Stage count the adaptive policy picks for spring constant k: max(4, pow2ceil(k / 2.5)). */
-int32_t topolow_slab_stages_for_k(double k);
-/* Stage count of iteration `iter` (0-based) at spring constant k when slab_stages = 0: the policy above,
- * and at least 16 stages during the first 16 iterations, while the layout unfolds from its start. */
-int32_t topolow_slab_stages_at(int32_t iter, double k);
+/* Stage count the adaptive policy picks for spring constant k in ndim dimensions: the smallest power of two
+ * with k / stages <= min(2.5, ndim) (a stage is a Jacobi step, stable for k / stages < 2 ndim). */
+int32_t topolow_slab_stages_for_k(double k, int32_t ndim);
+/* Stage count of iteration `iter` (0-based) when slab_stages = 0: the policy above, and at least 16 stages
+ * during the first 16 iterations, while the layout unfolds from its start. */
+int32_t topolow_slab_stages_at(int32_t iter, double k, int32_t ndim);
 /* Visiting order of the GS tournament schedule for iteration `iter`: n(n-1)/2 pairs
  * (a,b) as 2 int32 each, in an order equivalent to what the kernel executes. */
 int64_t topolow_gs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_t* pairs_out);
 /* fp32 target encoding used in HBM: value with the 2 low mantissa bits replaced by the
  * threshold code (0 exact, 1 ">", 2 "<", 3 skip); +Inf = unmeasured. */
 uint32_t topolow_encode_target(double dissimilarity, int32_t threshold_code);
+int64_t topolow_encoded_index(int32_t row_in_block, int32_t column, int32_t ld);
 double topolow_decode_target(uint32_t bits, int32_t* threshold_code);
 /* Convergence controller (reference src/optimization.cpp:303-357) on a scripted MAE
  * sequence; same code the device runs. */

@@ -42,7 +42,7 @@ def random_problem(n, dim, missing, seed, thresholds=0.0, n_iter=20, k0=3.0, coo
                                     True), prob
 
 
-def cfg3_generator(n, censored=0.0, n_iter=1000, eps=1e-4, window=5, check_freq=3):
+def cfg3_generator(n, censored=0.0, n_iter=1000, eps=1e-4, window=5, check_freq=3, k0=5.0, cool=0.01, c_rep=0.01):
     """BASELINE config 3's generator and parameters at `n` points; `censored`:
     fraction of the measured pairs turned into ">" censoring at the 90th percentile (config 3b)."""
     dim = 5
@@ -61,7 +61,7 @@ def cfg3_generator(n, censored=0.0, n_iter=1000, eps=1e-4, window=5, check_freq=
         m.values[ju[sel], iu[sel]] = m.values[iu[sel], ju[sel]]
         m.codes[iu[sel], ju[sel]] = 1
         m.codes[ju[sel], iu[sel]] = 1
-    call = core.prepare_layout_call(m, dim, n_iter, 5.0, 0.01, 0.01, eps, window, init, False, check_freq, True)
+    call = core.prepare_layout_call(m, dim, n_iter, k0, cool, c_rep, eps, window, init, False, check_freq, True)
     return call, prob
 
 
@@ -81,8 +81,8 @@ def _syn1500():
     return call, prob.dissimilarity
 
 
-def _cfg3gen(n, censored=0.0, eps=1e-4):
-    call, prob = cfg3_generator(n, censored, eps=eps)
+def _cfg3gen(n, censored=0.0, eps=1e-4, **kw):
+    call, prob = cfg3_generator(n, censored, eps=eps, **kw)
     return call, (prob.dissimilarity if censored == 0 else None)
 
 
@@ -100,6 +100,9 @@ PROBLEMS = {
                                  doc="cfg3_generator(1500, eps=1e-6)"),
     "cfg3gen_1500_eps1e-10": dict(fn=functools.partial(_cfg3gen, 1500, 0.0, 1e-10),
                                   doc="cfg3_generator(1500, eps=1e-10)"),
+    # a soft, slowly cooling spring: after the unfolding phase every iteration is ONE Jacobi sweep (k <= 2.5)
+    "cfg3gen_1500_lowk": dict(fn=functools.partial(_cfg3gen, 1500, 0.0, 1e-4, k0=2.0, cool=0.004, c_rep=0.01),
+                              doc="cfg3_generator(1500, k0=2.0, cool=0.004)"),
     "h3n2_ndim4": dict(fn=lambda: (h3n2_call(4), None), doc="Smith-2004 H3N2 panel (tests/golden/"
                        "h3n2_distances.csv), ndim 4, published parameters, start positions default_rng(7)"),
     "h3n2_ndim5": dict(fn=lambda: (h3n2_call(5), None), doc="the same, ndim 5 (BASELINE config 2)"),

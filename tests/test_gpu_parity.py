@@ -109,7 +109,7 @@ def _model_run(call, seed, stages_fixed, n_iter, arith):
     plans, counts = [], []
     k = call.k0
     for it in range(n_iter):
-        st = stages_fixed if stages_fixed else _native.slab_stages_at(it, k)
+        st = stages_fixed if stages_fixed else _native.slab_stages_at(it, k, call.initial_positions.shape[1])
         p = _native.slab_plan(n, st, seed, it)
         plans.append(p); counts.append(len(p))
         k *= 1.0 - call.cooling_rate

@@ -246,9 +246,9 @@ def load() -> C.CDLL:
     lib.topolow_slab_plan.restype = C.c_int32
     lib.topolow_slab_plan.argtypes = [C.c_int32, C.c_int32, C.c_uint64, C.c_int32, ip, C.c_int32]
     lib.topolow_slab_stages_for_k.restype = C.c_int32
-    lib.topolow_slab_stages_for_k.argtypes = [C.c_double]
+    lib.topolow_slab_stages_for_k.argtypes = [C.c_double, C.c_int32]
     lib.topolow_slab_stages_at.restype = C.c_int32
-    lib.topolow_slab_stages_at.argtypes = [C.c_int32, C.c_double]
+    lib.topolow_slab_stages_at.argtypes = [C.c_int32, C.c_double, C.c_int32]
     lib.topolow_gs_pair_order.restype = C.c_int64
     lib.topolow_gs_pair_order.argtypes = [C.c_int32, C.c_uint64, C.c_int32, ip]
     lib.topolow_encode_target.restype = C.c_uint32
@@ -592,12 +592,12 @@ def slab_plan(n: int, slab_stages: int, seed: int, it: int) -> np.ndarray:
     return buf[:ns].copy()
 
 
-def slab_stages_for_k(k: float) -> int:
-    return int(load().topolow_slab_stages_for_k(float(k)))
+def slab_stages_for_k(k: float, ndim: int = 5) -> int:
+    return int(load().topolow_slab_stages_for_k(float(k), int(ndim)))
 
 
-def slab_stages_at(it: int, k: float) -> int:
-    return int(load().topolow_slab_stages_at(int(it), C.c_double(k)))
+def slab_stages_at(it: int, k: float, ndim: int = 5) -> int:
+    return int(load().topolow_slab_stages_at(int(it), float(k), int(ndim)))
 
 
 def gs_pair_order(n: int, seed: int, it: int) -> np.ndarray:

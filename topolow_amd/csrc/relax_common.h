@@ -57,6 +57,36 @@ TL_HD inline double decode_target(uint32_t w, int* code) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Layout of an encoded block in HBM.  Production: row-major, rows x ld words, ld % 64 == 0.
+// Every kernel addresses the block through enc_index / enc_col_offset_bytes, so a layout is one
+// definition.  Tried on MI355X and NOT kept (-DTOPOLOW_ENC_TILED=1 builds it): "row-group tiles" -- the
+// 8 x 256 words of a (workgroup's rows, 256-column group) tile contiguous, a workgroup's tiles one
+// after another, so that a workgroup streams ONE contiguous region instead of eight rows ld * 4 bytes
+// apart.  Bit-identical results; config 3 (one 400-MB sweep per iteration) 66.6 instead of 64.6 us per
+// launch, config 4 on one GPU 513 instead of 500 iterations/s: within the box-to-box spread either way.
+// ---------------------------------------------------------------------------------------
+#ifndef TOPOLOW_ENC_TILED
+#define TOPOLOW_ENC_TILED 0
+#endif
+#if TOPOLOW_ENC_TILED
+constexpr int kEncLdAlign = 256;
+constexpr int kEncRowAlign = 8;
+TL_HD inline size_t enc_index(int row_in_block, int c, int ld) {
+  return (size_t)(row_in_block >> 3) * ((size_t)8 * (size_t)ld) + (size_t)(c >> 8) * 2048 +
+         (size_t)(row_in_block & 7) * 256 + (size_t)(c & 255);
+}
+// byte offset of column c from the first word of its row (enc_index(row, 0, ld))
+TL_HD inline int enc_col_offset_bytes(int c) { return ((c >> 8) << 13) | ((c & 255) << 2); }
+TL_HD inline int enc_row_span_bytes(int row_in_block, int ld) { return (8 * ld - (row_in_block & 7) * 256) * 4; }
+#else
+constexpr int kEncLdAlign = 64;
+constexpr int kEncRowAlign = 1;
+TL_HD inline size_t enc_index(int row_in_block, int c, int ld) { return (size_t)row_in_block * (size_t)ld + (size_t)c; }
+TL_HD inline int enc_col_offset_bytes(int c) { return c * 4; }
+TL_HD inline int enc_row_span_bytes(int, int ld) { return ld * 4; }
+#endif
+
+// ---------------------------------------------------------------------------------------
 // Counter-based random numbers for schedules (same stream on host and device).
 // ---------------------------------------------------------------------------------------
 TL_HD inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
@@ -127,11 +157,20 @@ TL_HD inline SlabRanges slab_ranges(const SlabGeom& g, uint64_t seed, int iter, 
   return r;
 }
 
-// Adaptive stage count: stable for k/S <~ 5 in the schedule study (tests/study), used with a
-// 2x margin; never fewer than 4 stages.
-TL_HD inline int slab_stages_for_k(double k) {
-  int s = 4;
-  while ((double)s * 2.5 < k && s < kMaxStages) s <<= 1;
+// Adaptive stage count.  Within a stage the updates are Jacobi: every point sums its own halves over the
+// slab from frozen positions.  Linearised around a fit, a stage multiplies the position error by
+// I - a L, L the (direction-weighted) Laplacian of the measured pairs; with per-pair gain
+// a = 2k / (4 g + k) and about g partners per point its largest eigenvalue is about (k / S) / d in d
+// dimensions (2 G / d with G = k / (2 S), both endpoints move), so a stage is stable for k / S < 2 d.  In the
+// schedule study (tests/study) the slab schedule was stable for k / S <~ 5 at d = 3 and 5.  The policy keeps
+// k / S <= min(2.5, d): a factor 2 inside either bound.  No other floor: once k <= 2.5 (d >= 3) an iteration is
+// ONE sweep -- one 4 N^2-byte launch instead of four (config 3: 0.61 instead of 0.48 of HBM peak) -- and the
+// final-MAE statistics are those of 4 stages to 1e-4 (32 seeds on each pinned problem,
+// tests/study/gpu_minstage_study.py): what decides the result happens in the first iterations, see below.
+TL_HD inline int slab_stages_for_k(double k, int ndim) {
+  const double per_stage = ndim < 3 ? (double)(ndim < 1 ? 1 : ndim) : 2.5;
+  int s = 1;
+  while ((double)s * per_stage < k && s < kMaxStages) s <<= 1;
   return s;
 }
 
@@ -143,8 +182,8 @@ TL_HD inline int slab_stages_for_k(double k) {
 // after iteration 16 no longer moves the result (same seeds end within 1e-4 of each other).
 constexpr int kEarlyIters = 16;
 constexpr int kEarlyStages = 16;
-TL_HD inline int slab_stages_at(int iter, double k) {
-  const int s = slab_stages_for_k(k);
+TL_HD inline int slab_stages_at(int iter, double k, int ndim) {
+  const int s = slab_stages_for_k(k, ndim);
   return (iter < kEarlyIters && s < kEarlyStages) ? kEarlyStages : s;
 }
 

@@ -91,8 +91,12 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // One encoded row as a buffer resource (wave-uniform, lives in 4 SGPRs): loads then need only a
 // 32-bit lane offset instead of a 64-bit address per row.
 typedef __amdgpu_buffer_rsrc_t row_rsrc_t;
-__device__ __forceinline__ row_rsrc_t make_row_rsrc(const uint32_t* row, int ld) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), /*stride*/ 0, ld * 4, 0x00020000);
+// `block` = first word of the encoded block, row_in_block = row - row_begin; the resource spans the row's
+// words (relax_common.h: enc_index), column c sits enc_col_offset_bytes(c) in.
+__device__ __forceinline__ row_rsrc_t make_row_rsrc(const uint32_t* block, int row_in_block, int ld) {
+  const uint32_t* row = block + enc_index(row_in_block, 0, ld);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), /*stride*/ 0,
+                                           enc_row_span_bytes(row_in_block, ld), 0x00020000);
 }
 __device__ __forceinline__ uint4 load_words(row_rsrc_t rsrc, int byte_off) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -398,7 +402,7 @@ __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>
     // land in the same registers).  Unconditional: the count of loads per chunk is what
     // pipe_await_points relies on; past the slab's end the offset is out of range, which a buffer
     // load answers with 0 without touching memory.
-    const int noff = g * 256 < ncw ? (ncb + c4) * 4 : 0x7ffffff0;
+    const int noff = g * 256 < ncw ? enc_col_offset_bytes(ncb + c4) : 0x7ffffff0;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) w[g][r] = load_words(R.rsrc[r], noff);
   }
@@ -407,7 +411,7 @@ __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>
 }
 
 // One slab stage for rows [row_begin,row_end).
-//   denc    : (row_end-row_begin) x ld encoded targets, row-major, ld % 64 == 0
+//   denc    : (row_end-row_begin) x ld encoded targets (layout: relax_common.h enc_index), ld % 64 == 0
 //   pos_in  : n x DIM row-major, all points, read-only in this launch
 //   pos_out : n x DIM row-major; rows [row_begin,row_end) are written
 //   st      : run state (nullable): launch is a no-op once st->stopped is set; non-finite
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
   for (int r = 0; r < RPW; ++r) {
     const int row = row0 + r;
     rr[r] = row < row_end ? row : row_end - 1;  // clamp: result discarded below
-    R.rsrc[r] = make_row_rsrc(denc + (size_t)(rr[r] - row_begin) * ld, ld);
+    R.rsrc[r] = make_row_rsrc(denc, rr[r] - row_begin, ld);
   }
   // first chunk's points and target words are on their way before anything else
   int cb, cw;
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
   uint4 w[G::GPC][RPW];
 #pragma unroll
   for (int g = 0; g < G::GPC; ++g) {
-    const int off = g * 256 < cw ? (cb + g * 256 + lane * 4) * 4 : 0x7ffffff0;
+    const int off = g * 256 < cw ? enc_col_offset_bytes(cb + g * 256 + lane * 4) : 0x7ffffff0;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) w[g][r] = load_words(R.rsrc[r], off);
   }
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
       thr_any |= rowflags[rr - row_begin];
 #pragma unroll
       for (int d = 0; d < DIM; ++d) pi[r][d] = uniform(pos[(size_t)rr * DIM + d]);
-      rsrc[r] = make_row_rsrc(denc + (size_t)(rr - row_begin) * ld, ld);
+      rsrc[r] = make_row_rsrc(denc, rr - row_begin, ld);
     }
     const bool thr = __builtin_amdgcn_readfirstlane(thr_any) != 0;
     // all of this row batch's target words are requested before any is used (the points are
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(CFG::THREADS) void dense_error_kernel(
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const bool need = c4 < cw && (PARITY || cb + c4 + 3 > rows[r]) && rows[r] != 0x7fffffff;
-        w4[t][r] = need ? load_words(rsrc[r], (cb + c4) * 4) : make_uint4(kInfWord, kInfWord, kInfWord, kInfWord);
+        w4[t][r] = need ? load_words(rsrc[r], enc_col_offset_bytes(cb + c4)) : make_uint4(kInfWord, kInfWord, kInfWord, kInfWord);
       }
     }
     if constexpr (sizeof(real) == 4 && RPW == 2 && !PARITY) {
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(kThreads) void encode_dense_kernel(
     const size_t cell = (size_t)lo + (size_t)hi * n;
     w = encode_target(D[cell], T[cell]);
   }
-  out[(size_t)(i - row_begin) * ld + c] = w;
+  out[enc_index(i - row_begin, c, ld)] = w;
 }
 
 // Order-independent fingerprint of the measured cells the dense MAE pass would reduce, used to
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(kThreads) void upper_fingerprint_kernel(
   unsigned long long fp = 0, cnt = 0;
   for (int c = threadIdx.x; c < n; c += kThreads) {
     if (c == i || !dense_takes(i, c, parity != 0)) continue;
-    const uint32_t w = enc[(size_t)(i - row_begin) * ld + c];
+    const uint32_t w = enc[enc_index(i - row_begin, c, ld)];
     if (w == kInfWord) continue;
     fp += cell_fingerprint(i < c ? i : c, i < c ? c : i, w);
     ++cnt;
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(kThreads) void row_flags_kernel(const uint32_t* __r
   if (i >= rows) return;
   int any = 0;
   for (int c = threadIdx.x; c < ld; c += kThreads) {
-    const uint32_t w = enc[(size_t)i * ld + c];
+    const uint32_t w = enc[enc_index(i, c, ld)];
     const uint32_t code = w & kCodeMask;
     any |= (code == 1u) | ((code == 2u) & (w != kInfWord));
   }
@@ -989,7 +993,7 @@ __global__ __launch_bounds__(kThreads) void fill_unmeasured_kernel(
   const int c = blockIdx.y * kThreads + threadIdx.x;   // grid: x = row, y = 256-column group
   const int i = row_begin + blockIdx.x;
   if (c >= ld || i >= row_end) return;
-  out[(size_t)(i - row_begin) * ld + c] = kInfWord;
+  out[enc_index(i - row_begin, c, ld)] = kInfWord;
 }
 
 __global__ __launch_bounds__(kThreads) void scatter_edges_kernel(
@@ -1003,8 +1007,8 @@ __global__ __launch_bounds__(kThreads) void scatter_edges_kernel(
   if (a == b || a < 0 || b < 0 || a >= n || b >= n) return;
   if (inv != nullptr) { a = inv[a]; b = inv[b]; }
   const uint32_t w = encode_target(ed[e], ec[e]);
-  if (a >= row_begin && a < row_end) out[(size_t)(a - row_begin) * ld + b] = w;
-  if (b >= row_begin && b < row_end) out[(size_t)(b - row_begin) * ld + a] = w;
+  if (a >= row_begin && a < row_end) out[enc_index(a - row_begin, b, ld)] = w;
+  if (b >= row_begin && b < row_end) out[enc_index(b - row_begin, a, ld)] = w;
 }
 
 // est_distances = as.matrix(dist(positions)) (reference R/core.R:474), f64, rows [row0, row0 + rows).

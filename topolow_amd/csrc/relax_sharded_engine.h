@@ -121,7 +121,7 @@ inline void sharded_worker(ShardedRun& R, int r) {
     }
     if (r == 0 && R.interrupt_cb != nullptr && iter > 0 && iter % 50 == 0 && !R.interrupted)   // reference :364
       R.interrupted = R.interrupt_cb(R.interrupt_user) != 0;   // published at the next exchange
-    const int stages = R.fixed_stages > 0 ? R.fixed_stages : slab_stages_at(iter, k);
+    const int stages = R.fixed_stages > 0 ? R.fixed_stages : slab_stages_at(iter, k, lead->dim);
     const SlabGeom geo = slab_geom(lead->n, stages);
     for (int slot = 0; slot < geo.n_stages; ++slot) {
       const SlabRanges rg = slab_ranges(geo, lead->seed, iter, slot);

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kTile) void tilegs_pair_kernel(
   gj[lane] = j_own < n ? gplus[j_own] : 1.0f;
   // row i of the tile: 64 consecutive words (16-byte loads), into LDS row `lane`
   if (vi) {
-    const uint4* src = reinterpret_cast<const uint4*>(enc + (size_t)i * ld + (size_t)bj * kTile);
+    const uint4* src = reinterpret_cast<const uint4*>(enc + enc_index(i, bj * kTile, ld));
 #pragma unroll
     for (int q = 0; q < kTile / 4; ++q) {
       const uint4 v = src[q];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kTile) void tilegs_intra_kernel(
   for (int d = 0; d < DIM; ++d) pb[lane][d] = vi ? pos[(size_t)i * DIM + d] : (real)0;
   gb[lane] = vi ? gplus[i] : 1.0f;
   if (vi) {
-    const uint4* src = reinterpret_cast<const uint4*>(enc + (size_t)i * ld + (size_t)b * kTile);
+    const uint4* src = reinterpret_cast<const uint4*>(enc + enc_index(i, b * kTile, ld));
 #pragma unroll
     for (int q = 0; q < kTile / 4; ++q) {
       const uint4 v = src[q];

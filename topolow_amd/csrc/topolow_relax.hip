@@ -653,6 +653,10 @@ void topolow_default_options(topolow_options* opt) {
   opt->interrupt_user = nullptr;
 }
 
+int64_t topolow_encoded_index(int32_t row_in_block, int32_t column, int32_t ld) {
+  return (int64_t)enc_index(row_in_block, column, ld);
+}
+
 uint32_t topolow_encode_target(double dissimilarity, int32_t threshold_code) {
   return encode_target(dissimilarity, threshold_code);
 }
@@ -663,8 +667,8 @@ double topolow_decode_target(uint32_t bits, int32_t* threshold_code) {
   return v;
 }
 
-int32_t topolow_slab_stages_for_k(double k) { return slab_stages_for_k(k); }
-int32_t topolow_slab_stages_at(int32_t iter, double k) { return slab_stages_at(iter, k); }
+int32_t topolow_slab_stages_for_k(double k, int32_t ndim) { return slab_stages_for_k(k, ndim); }
+int32_t topolow_slab_stages_at(int32_t iter, double k, int32_t ndim) { return slab_stages_at(iter, k, ndim); }
 
 int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t iter,
                           int32_t* ranges_out, int32_t max_stages) {
@@ -729,7 +733,7 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     s->dim = ndim;
     s->row_begin = row_begin;
     s->row_end = row_end;
-    s->ld = (n + 63) & ~63;
+    s->ld = (n + kEncLdAlign - 1) & ~(kEncLdAlign - 1);
     s->precision = precision == TOPOLOW_PRECISION_F64 ? TOPOLOW_PRECISION_F64
                                                       : TOPOLOW_PRECISION_F32;
     HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
@@ -739,7 +743,7 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     HIP_TRY(hipEventCreateWithFlags(&s->ev_check_done, hipEventDisableTiming));
     const char* serial = getenv("TOPOLOW_SERIAL_CHECKS");
     s->serial_checks = serial != nullptr && serial[0] == '1';
-    s->enc.alloc((size_t)s->rows() * s->ld);
+    s->enc.alloc((size_t)((s->rows() + kEncRowAlign - 1) / kEncRowAlign * kEncRowAlign) * s->ld);
     const size_t pos_bytes = (size_t)s->pos_rows() * ndim * s->real_size();
     for (auto& b : s->pos) b.alloc(pos_bytes);
     s->best.alloc(pos_bytes);
@@ -1060,7 +1064,7 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
       if (s->schedule == TOPOLOW_SCHEDULE_GS) {
         TL_DISPATCH_DIM(s->dim, launch_tilegs_iteration, s, s->pos[s->cur].p, iter, s->k_host);
       } else {
-        const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_at(iter, s->k_host);
+        const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_at(iter, s->k_host, s->dim);
         const SlabGeom g = slab_geom(s->n, stages);
         for (int slot = 0; slot < g.n_stages; ++slot) {
           const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);

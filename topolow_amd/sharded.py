@@ -215,7 +215,7 @@ def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, ini
     t_stage = t_gather = t_check = 0.0
     checks = 0
     for it in range(n_iter):
-        stages = slab_stages if slab_stages > 0 else _native.slab_stages_at(it, k)
+        stages = slab_stages if slab_stages > 0 else _native.slab_stages_at(it, k, int(np.asarray(initial_positions).shape[1]))
         n_slots = len(_native.slab_plan(n, stages, seed, it))
         for slot in range(n_slots):
             if timers:   # breakdown pass: host-synchronised, so slower than the timed pass
@@ -299,7 +299,8 @@ def load_synthetic_block(backend: HipBackend, n: int, latent_dim: int, missing: 
     b, e = rows if rows is not None else row_block(n, world, rank)[:2]
     ld = s.encoded_ld
     rows = e - b
-    # view the session's HBM block as a torch tensor
+    # view the session's HBM block as a torch tensor (row-major, include/topolow_relax.h:
+    # topolow_session_encoded_ptr)
     enc = _as_tensor(torch, s.encoded_ptr, (rows, ld), torch.int32, dev)
     thresh = int(missing * 0x7FFFFFFF)
     cols = torch.arange(n, device=dev, dtype=torch.int64)
