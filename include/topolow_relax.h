@@ -279,6 +279,11 @@ int topolow_session_check_trace(topolow_session* s, double* out, int32_t max_che
  * topolow_session_profile waits for the stream, returns the summed durations (ms) and launch
  * counts since profiling was enabled, and resets them. */
 int topolow_session_set_profiling(topolow_session* s, int32_t enable);
+/* Of the stage launches recorded so far, those that also reduced a convergence check's MAE (one-stage
+ * iterations: the check is fused into the next iteration's sweep) -- summed duration (ms) and count.  Does
+ * not reset anything: ask before topolow_session_profile, whose stage figures include these launches. */
+int topolow_session_profile_fused(topolow_session* s, double* fused_ms, int64_t* fused_launches, char* errbuf,
+                                  size_t errlen);
 int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage_launches,
                             double* check_ms, int64_t* checks, char* errbuf, size_t errlen);
 /* external != 0: the session launches on the caller's stream `hip_stream` (a hipStream_t; NULL

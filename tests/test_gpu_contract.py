@@ -57,7 +57,7 @@ def check_runs(name, runs, mean_band=None, schedule=None):
     return got
 
 
-@pytest.mark.parametrize("name", ["syn1500_h3n2params", "cfg3gen_1500", "cfg3gen_2048", "cfg3b_1500"])
+@pytest.mark.parametrize("name", ["syn1500_h3n2params", "cfg3gen_1500", "cfg3gen_2048", "cfg3b_1500", "cfg3gen_1500_lowk"])
 def test_slab_schedule_meets_the_contract(name):
     """The fast path (AUTO above 1024 points): row-owner slabs, fp32, random labels."""
     call, _ = pp.build(name)

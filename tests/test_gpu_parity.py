@@ -233,6 +233,47 @@ def test_checks_beside_next_iteration_change_nothing(monkeypatch):
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
 
 
+def test_check_fused_into_the_next_iterations_sweep(monkeypatch):
+    """Once k <= 2.5 an iteration is ONE stage, and that stage meets every pair from the positions the previous
+    iteration left -- the positions the previous iteration's convergence check measures.  The kernel then reduces
+    the check's MAE on its way (ERR launch) and the separate pass over the block is dropped;
+    TOPOLOW_FUSE_CHECKS=0 keeps the separate pass.  Same trajectory and verdicts; the MAE agrees to fp32 rounding
+    (it is the oracle's edge MAE of the returned positions either way).  Thresholds, a check every iteration, a
+    run that exhausts its iterations (its last check has no next iteration: separate pass) and the caller-paced
+    form (enqueue / sync between checks: a pending check is flushed) included."""
+    call, _ = _random_problem(1200, 3, 0.6, seed=31, thresholds=0.1, n_iter=400, k0=2.4, cool=0.02, c_rep=0.01)
+    outs = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("TOPOLOW_FUSE_CHECKS", fuse)
+        rows = []
+        for n_iter, window, freq, paced in ((400, 3, 3, False), (400, 2, 1, False), (41, 50, 2, False), (400, 3, 3, True)):
+            s = _native.Session(1200, 3, precision="f32")
+            s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+            s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+            assert s.uses_dense_mae
+            s.set_positions(call.initial_positions)
+            s.begin(n_iter, 2.4, 0.02, 0.01, 1e-3, window, freq, 5, 0)
+            if paced:
+                while s.enqueue(3) > 0:
+                    s.sync()
+            else:
+                s.run()
+            r = s.finish()
+            trace = s.check_trace()
+            rows.append((r.positions.copy(), r.converged, r.iterations, r.final_mae, r.final_k, trace))
+            s.close()
+        outs[fuse] = rows
+    assert outs["1"][0][1] and outs["1"][1][1] and not outs["1"][2][1]     # two stops, one exhausted run
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a[0], b[0]) and a[1:3] == b[1:3] and a[4] == b[4]
+        assert a[3] == pytest.approx(b[3], rel=2e-6)
+        assert a[5].shape == b[5].shape and np.array_equal(a[5][:, 0], b[5][:, 0])
+        assert np.allclose(a[5][:, 1], b[5][:, 1], rtol=2e-6, atol=0)
+    got = outs["1"][0]
+    sm, cnt = orc.edge_error(got[0], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert got[3] == pytest.approx(sm / cnt, rel=2e-5)
+
+
 # ----------------------------------------------------------------------------------------
 # slab schedule end-to-end vs the reference schedule (statistical), plus post metrics
 # ----------------------------------------------------------------------------------------

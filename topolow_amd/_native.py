@@ -149,6 +149,9 @@ def load() -> C.CDLL:
     i64p = C.POINTER(C.c_int64)
     lib.topolow_cv_fold.argtypes = [C.POINTER(TopolowCellList), i64p, C.c_int64, C.c_int32, C.c_int32, ip, ip,
                                     ip, ip, dp, ip, i64p, ip, ip, dp, i64p, dp]
+    lib.topolow_session_profile_fused.restype = C.c_int
+    lib.topolow_session_profile_fused.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_char_p,
+                                                  C.c_size_t]
     lib.topolow_session_set_relabel.restype = C.c_int
     lib.topolow_session_set_relabel.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
     lib.topolow_session_labels.restype = C.c_int
@@ -789,6 +792,13 @@ class Session:
         _check(self.lib.topolow_session_profile(self._h, C.byref(sm), C.byref(sl), C.byref(cm),
                                                 C.byref(cl), self._err, len(self._err)), self._err)
         return float(sm.value), int(sl.value), float(cm.value), int(cl.value)
+
+    def profile_fused(self):
+        """(ms, launches) of the stage launches that also reduced a check's MAE; ask before profile()."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        _check(self.lib.topolow_session_profile_fused(self._h, C.byref(ms), C.byref(n), self._err, len(self._err)),
+               self._err)
+        return float(ms.value), int(n.value)
 
     def set_stream(self, hip_stream, external: bool = True):
         """hip_stream: integer hipStream_t (0/None = the device's default stream)."""

@@ -156,9 +156,10 @@ __device__ __forceinline__ void load_points(const real* lds_pos, int c4, real (&
 //   ks = 2k / (4 g_i + k), cg = (c_rep / 2) / g_i   (row constants, scalar registers)
 //   THR = false: the row holds no ">" / "<" targets (flag computed when the matrix is encoded),
 //   so a pair springs exactly when it is measured (target < +Inf).
-template <int DIM, typename real, bool THR>
+template <int DIM, typename real, bool THR, bool ERR = false>
 __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&pi)[DIM],
-                                           uint32_t w, real ks, real cg, real (&acc)[DIM]) {
+                                           uint32_t w, real ks, real cg, real (&acc)[DIM],
+                                           float* err = nullptr, unsigned* cnt_wave = nullptr) {
   real dx[DIM];
   real s = 0;
 #pragma unroll
@@ -186,6 +187,12 @@ __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&p
   const real coef = spring ? fs : fr;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc[d] = fma(dx[d], coef, acc[d]);
+  if constexpr (ERR) {
+    // the convergence MAE of the positions this stage reads: a pair contributes exactly when its spring is
+    // active (reference src/optimization.cpp:68-76 and :230-243 are the same three cases)
+    *err += spring ? (float)fabs(t - r) : 0.0f;
+    *cnt_wave += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(spring));
+  }
 }
 
 #ifdef TOPOLOW_TUNING
@@ -284,23 +291,28 @@ struct PipeRows {
     ks[r] = ks_r;
     cg[r] = cg_r;
   }
+  float err = 0.0f;          // ERR launches: this lane's |t - r| over its contributing pairs (folded by the caller)
+  unsigned cnt_wave = 0;     // ... and the wave's count of them (wave-uniform)
+
   // four column points against every row; w[r] = the rows' target words of those columns
+  template <bool ERR>
   __device__ __forceinline__ void group(const real (&pc)[4][DIM], const uint4 (&w)[RPW]) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       if (ANYTHR && thr) {
-        pair_accum<DIM, real, true>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r]);
-        pair_accum<DIM, real, true>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r]);
-        pair_accum<DIM, real, true>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r]);
-        pair_accum<DIM, real, true>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, true, ERR>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, true, ERR>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, true, ERR>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, true, ERR>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r], &err, &cnt_wave);
       } else {
-        pair_accum<DIM, real, false>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r]);
-        pair_accum<DIM, real, false>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r]);
-        pair_accum<DIM, real, false>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r]);
-        pair_accum<DIM, real, false>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r]);
+        pair_accum<DIM, real, false, ERR>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, false, ERR>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, false, ERR>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, false, ERR>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r], &err, &cnt_wave);
       }
     }
   }
+  __device__ __forceinline__ double take_err() { const double e = (double)err; err = 0.0f; return e; }
   __device__ __forceinline__ real origin(int r, int d) const { return pi[r][d]; }
   __device__ __forceinline__ real lane_sum(int r, int d) const { return acc[r][d]; }
 };
@@ -312,10 +324,11 @@ struct PipeRows {
 // generic form (bit-identical results).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-template <int DIM, bool THR>
+template <int DIM, bool THR, bool ERR = false>
 __device__ __forceinline__ void pair_accum_rows2(const float (&pc)[DIM], const f32x2_t (&pi2)[DIM],
                                                  uint32_t w0, uint32_t w1, f32x2_t ks2, f32x2_t cg2,
-                                                 f32x2_t (&acc2)[DIM]) {
+                                                 f32x2_t (&acc2)[DIM], f32x2_t* err2 = nullptr,
+                                                 unsigned* cnt_wave = nullptr) {
   f32x2_t dx[DIM];
   f32x2_t s = {0.0f, 0.0f};
 #pragma unroll
@@ -337,11 +350,18 @@ __device__ __forceinline__ void pair_accum_rows2(const float (&pc)[DIM], const f
     sp0 = __builtin_amdgcn_classf(bits_f32(w0), 0x1f8);
     sp1 = __builtin_amdgcn_classf(bits_f32(w1), 0x1f8);
   }
-  const f32x2_t fs = (t - r) * inv * ks2;
+  const f32x2_t e = t - r;
+  const f32x2_t fs = e * inv * ks2;
   const f32x2_t fr = inv * inv * inv * cg2;
   const f32x2_t coef = {sp0 ? fs.x : fr.x, sp1 ? fs.y : fr.y};
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc2[d] = __builtin_elementwise_fma(dx[d], coef, acc2[d]);
+  if constexpr (ERR) {   // see pair_accum
+    const f32x2_t a = {sp0 ? fabsf(e.x) : 0.0f, sp1 ? fabsf(e.y) : 0.0f};
+    *err2 += a;
+    *cnt_wave += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sp0)) +
+                 (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sp1));
+  }
 }
 
 template <int DIM, bool ANYTHR>
@@ -351,6 +371,8 @@ struct PipeRows<DIM, float, 2, ANYTHR, true> {
   f32x2_t ks2, cg2;
   row_rsrc_t rsrc[2];
   bool thr;
+  f32x2_t err2 = {0.0f, 0.0f};   // ERR launches: see the generic form
+  unsigned cnt_wave = 0;
 
   __device__ __forceinline__ void set_row(int r, const float (&p)[DIM], float ks_r, float cg_r) {
 #pragma unroll
@@ -359,18 +381,24 @@ struct PipeRows<DIM, float, 2, ANYTHR, true> {
     }
     if (r == 0) { ks2.x = ks_r; cg2.x = cg_r; } else { ks2.y = ks_r; cg2.y = cg_r; }
   }
+  template <bool ERR>
   __device__ __forceinline__ void group(const float (&pc)[4][DIM], const uint4 (&w)[2]) {
     if (ANYTHR && thr) {
-      pair_accum_rows2<DIM, true>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2);
-      pair_accum_rows2<DIM, true>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2);
-      pair_accum_rows2<DIM, true>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2);
-      pair_accum_rows2<DIM, true>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, true, ERR>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, true, ERR>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, true, ERR>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, true, ERR>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2, &err2, &cnt_wave);
     } else {
-      pair_accum_rows2<DIM, false>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2);
-      pair_accum_rows2<DIM, false>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2);
-      pair_accum_rows2<DIM, false>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2);
-      pair_accum_rows2<DIM, false>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2);
+      pair_accum_rows2<DIM, false, ERR>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, false, ERR>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, false, ERR>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, false, ERR>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2, &err2, &cnt_wave);
     }
+  }
+  __device__ __forceinline__ double take_err() {
+    const double e = (double)err2.x + (double)err2.y;
+    err2 = (f32x2_t){0.0f, 0.0f};
+    return e;
   }
   __device__ __forceinline__ float origin(int r, int d) const { return r == 0 ? pi2[d].x : pi2[d].y; }
   __device__ __forceinline__ float lane_sum(int r, int d) const { return r == 0 ? acc2[d].x : acc2[d].y; }
@@ -379,7 +407,7 @@ struct PipeRows<DIM, float, 2, ANYTHR, true> {
 // One chunk: request the next chunk's points into `oth`, sweep this chunk's groups out of `cur`.
 //   w : target words of this chunk's groups on entry, of the next chunk's groups on exit -- a
 //       group's words are requested GPC-1 groups and one barrier before their use
-template <int DIM, typename real, typename CFG, bool ANYTHR>
+template <int DIM, typename real, typename CFG, bool ANYTHR, bool ERR>
 __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>& R,
                                            const real* __restrict__ pos, int pos_bytes,
                                            const unsigned char* cur, unsigned char* oth, int cw,
@@ -396,7 +424,7 @@ __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>
     if (c4 < cw) {
       real pc[4][DIM];
       load_points<DIM, real>(lds_pos, c4, pc);
-      R.group(pc, w[g]);
+      R.template group<ERR>(pc, w[g]);
     }
     // The same group of the next chunk, requested as soon as this group's words are dead (so they
     // land in the same registers).  Unconditional: the count of loads per chunk is what
@@ -422,13 +450,19 @@ __device__ __forceinline__ void pipe_chunk(PipeRows<DIM, real, CFG::RPW, ANYTHR>
 //             all-gather of the updated slices is part of this kernel's epilogue
 //   ANYTHR = false: the host has checked that NO row of the block holds a threshold target,
 //   so only the cheaper classification is compiled in (fewer registers, one more wave per SIMD).
-template <int DIM, typename real, typename CFG, bool ANYTHR>
+//   ERR = true (one-stage iterations only): the launch also reduces the convergence MAE of the positions it
+//             READS -- with one stage per iteration every ordered pair is met from the positions the
+//             previous iteration left, which is what the reference's check of that iteration measures
+//             (src/optimization.cpp:294-296); each unordered pair is met twice with the same |t - r|, so
+//             sum and count double and their ratio is the MAE.  Per-workgroup partials in f64.
+template <int DIM, typename real, typename CFG, bool ANYTHR, bool ERR = false>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_kernel(
     const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
     const real* __restrict__ pos_in, real* __restrict__ pos_out,
     const float* __restrict__ gplus, const unsigned char* __restrict__ rowflags, RunState* st,
     SlabRanges rg, int iter1, double k, double c_rep, int falling_priority,
-    real* const* __restrict__ push, int n_push) {
+    real* const* __restrict__ push, int n_push, double* __restrict__ part_sum,
+    unsigned long long* __restrict__ part_cnt) {
   if (st != nullptr && st->stopped) return;
   TL_WG_STAMP(0);
   using G = PipeGeom<DIM, real, CFG::CHUNK>;
@@ -444,6 +478,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
   const int nch = nc0 + (rg.e1 - rg.b1 + G::CHUNK - 1) / G::CHUNK;
 
   PipeRows<DIM, real, RPW, ANYTHR> R;
+  double err_d = 0.0;
   int rr[RPW];
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
@@ -497,8 +532,30 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
       else if (left == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
-    pipe_chunk<DIM, real, CFG, ANYTHR>(R, pos_in, pos_bytes, cur, oth, cw, ncb, ncw, w, wave, lane);
+    pipe_chunk<DIM, real, CFG, ANYTHR, ERR>(R, pos_in, pos_bytes, cur, oth, cw, ncb, ncw, w, wave, lane);
     cw = ncw;
+    if constexpr (ERR) err_d += R.take_err();   // fp32 partial of one chunk (<= 32 terms per lane) into f64
+  }
+  if constexpr (ERR) {
+    // rows past the block's end were clamped onto its last row: their pairs must not count twice
+    double s = 0.0;
+    unsigned long long c = 0;
+    if (row0 + RPW - 1 < row_end) { s = wave_sum<double>(err_d); c = R.cnt_wave; }
+    else {
+      // ragged last wave: recount is not possible pair by pair here, so such a launch is never ERR
+      // (the host only fuses when the row block is a multiple of RPW rows)
+    }
+    double* red_s = reinterpret_cast<double*>(bufs);                       // the point buffers are free now
+    unsigned long long* red_c = reinterpret_cast<unsigned long long*>(bufs + 64);
+    if (lane == 0) { red_s[wave] = s; red_c[wave] = c; }
+    __syncthreads();
+    if (tid == 0) {
+      double ts = 0.0;
+      unsigned long long tc = 0;
+      for (int q = 0; q < CFG::WAVES; ++q) { ts += red_s[q]; tc += red_c[q]; }
+      part_sum[blockIdx.x] = ts;
+      part_cnt[blockIdx.x] = tc;
+    }
   }
 
 #pragma unroll

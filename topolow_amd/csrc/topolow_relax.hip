@@ -199,6 +199,11 @@ struct topolow_session {
   hipStream_t check_stream = nullptr;
   hipEvent_t ev_iter_done = nullptr, ev_check_done = nullptr;
   int held = -1;
+  // A convergence check whose error pass has not been launched yet: when the NEXT iteration is a single
+  // stage, that stage's kernel reduces the MAE of the positions it reads (exactly this check's positions)
+  // on its way (slab_stage_pipe_kernel<..., ERR = true>) and the separate 2 N^2-byte pass is dropped.
+  struct PendingCheck { bool active = false; int iter1 = 0; double k_after = 0.0; int buf = -1; bool beside = false; } pcheck;
+  bool fuse_checks = true;      // TOPOLOW_FUSE_CHECKS=0: always the separate pass
   bool serial_checks = false;   // TOPOLOW_SERIAL_CHECKS=1: keep every check on the main stream
 
   // Session labels.  With a relabelling (topolow_session_set_relabel) the session stores point
@@ -256,7 +261,7 @@ struct topolow_session {
   int n_ranks = 0, rank = 0;
   // profiling (roofline accounting)
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_stage, prof_check;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_stage, prof_stage_err, prof_check;   // _err: launches that also reduce the MAE
 
   size_t real_size() const { return precision == TOPOLOW_PRECISION_F64 ? 8 : 4; }
   int rows() const { return row_end - row_begin; }
@@ -264,6 +269,7 @@ struct topolow_session {
 
   ~topolow_session() {
     for (auto& pr : prof_stage) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : prof_stage_err) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : prof_check) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
@@ -357,7 +363,7 @@ int slab_variant() {
 
 template <int DIM, typename real, typename CFG>
 void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState* st,
-                       SlabRanges rg, int iter1, double k, const void* push, int n_push) {
+                       SlabRanges rg, int iter1, double k, const void* push, int n_push, bool err) {
   const int blocks = (s->rows() + CFG::ROWS - 1) / CFG::ROWS;
 #ifdef TOPOLOW_TUNING
   g_stamps.arm(blocks);
@@ -375,8 +381,22 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
     const int falling = blocks <= resident[which] ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), 0, s->stream, s->enc.p, s->ld,
                        s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
-                       s->rowflags.p, st, rg, iter1, k, s->c_rep, falling, (real* const*)push, n_push);
+                       s->rowflags.p, st, rg, iter1, k, s->c_rep, falling, (real* const*)push, n_push,
+                       s->part_sum.p, s->part_cnt.p);
   };
+  if constexpr (sizeof(real) == 4) {
+    if (err) {   // the launch also reduces the convergence MAE of the positions it reads (one-stage iterations)
+      if (s->any_threshold) {
+        constexpr int kThrWavesE = DIM >= 9 ? 3 : (DIM >= 5 ? 4 : 5);   // the error sums cost registers: 4 waves from ndim 5
+        using CfgThrE = StageCfg<CFG::THREADS, CFG::RPW, CFG::CHUNK, CFG::PRIO,
+                                 CFG::MINWAVES < kThrWavesE ? CFG::MINWAVES : kThrWavesE>;
+        launch(&slab_stage_pipe_kernel<DIM, real, CfgThrE, true, true>, 1);
+      } else {
+        launch(&slab_stage_pipe_kernel<DIM, real, CFG, false, true>, 0);
+      }
+      return;
+    }
+  }
   if (s->any_threshold) {
     // The instance that also carries the ">" / "<" classification needs more registers: from
     // ndim 7 on it would spill inside the pair loop at a 5-wave budget (9x slower at ndim 10), so
@@ -393,23 +413,23 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
 
 template <int DIM>
 void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st, SlabRanges rg,
-                  int iter1, double k, const void* push = nullptr, int n_push = 0) {
+                  int iter1, double k, const void* push = nullptr, int n_push = 0, bool err = false) {
   if (s->rows() <= 0) return;
-  ProfScope prof(s, &s->prof_stage);
+  ProfScope prof(s, err ? &s->prof_stage_err : &s->prof_stage);
   if (s->precision == TOPOLOW_PRECISION_F64) {
-    launch_stage_pipe<DIM, double, StageCfg<256, 2, 0, 1>>(s, pin, pout, st, rg, iter1, k, push, n_push);
+    launch_stage_pipe<DIM, double, StageCfg<256, 2, 0, 1>>(s, pin, pout, st, rg, iter1, k, push, n_push, false);
   } else {
 #ifdef TOPOLOW_TUNING
     switch (slab_variant()) {
-      case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
-      case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 1, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
-      case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 4>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
-      case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 1, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
-      case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 7>>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
-      default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push); break;
+      case 20: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 0, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      case 21: launch_stage_pipe<DIM, float, StageCfg<256, 2, 768, 1, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 4>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 1, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 7>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
     }
 #else
-    launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push);
+    launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push, err);
 #endif
   }
   HIP_TRY(hipGetLastError());
@@ -614,6 +634,41 @@ void launch_tilegs_finite(topolow_session* s, const void* pos, int iter1) {
   HIP_TRY(hipGetLastError());
 }
 
+// One convergence check of the session's own loop.  error_pass = true: the separate pass over the block (or
+// the edge list) + the controller; false: the partials were written by the stage kernel just launched
+// (ERR launch), only the controller follows.  pc.beside: on the check stream, beside the next stages.
+void launch_check(topolow_session* s, topolow_session::PendingCheck& pc, bool error_pass) {
+  hipStream_t check_on = s->stream;
+  if (pc.beside) {
+    HIP_TRY(hipEventRecord(s->ev_iter_done, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->check_stream, s->ev_iter_done, 0));
+    check_on = s->check_stream;
+  }
+  {
+    StreamScope on(s, check_on);
+    ProfScope prof(s, &s->prof_check);
+    if (error_pass) {
+      TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[pc.buf].p, s->state.p);
+      launch_controller(s, s->pos[pc.buf].p, pc.iter1, pc.k_after);
+    } else {
+      const int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
+      launch_controller(s, s->pos[pc.buf].p, pc.iter1, pc.k_after, s->part_sum.p, s->part_cnt.p, stage_blocks);
+    }
+  }
+  if (pc.beside) HIP_TRY(hipEventRecord(s->ev_check_done, check_on));
+  hipEvent_t e = take_event(s);
+  HIP_TRY(hipEventRecord(e, check_on));
+  s->pending.push_back(e);
+  poll_checks(s, 3);
+  pc.active = false;
+}
+
+// A check that was waiting for the next iteration's kernel and will not get one (the caller stopped
+// enqueueing, or asks for results): run it as a separate pass now.
+void flush_pending_check(topolow_session* s) {
+  if (s->pcheck.active) launch_check(s, s->pcheck, /*error_pass=*/true);
+}
+
 template <typename F>
 int guarded(char* errbuf, size_t errlen, F&& body) {
   try {
@@ -743,6 +798,8 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     HIP_TRY(hipEventCreateWithFlags(&s->ev_check_done, hipEventDisableTiming));
     const char* serial = getenv("TOPOLOW_SERIAL_CHECKS");
     s->serial_checks = serial != nullptr && serial[0] == '1';
+    const char* fuse = getenv("TOPOLOW_FUSE_CHECKS");
+    s->fuse_checks = !(fuse != nullptr && fuse[0] == '0');
     s->enc.alloc((size_t)((s->rows() + kEncRowAlign - 1) / kEncRowAlign * kEncRowAlign) * s->ld);
     const size_t pos_bytes = (size_t)s->pos_rows() * ndim * s->real_size();
     for (auto& b : s->pos) b.alloc(pos_bytes);
@@ -891,8 +948,9 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
     s->dense_grid_x = (((s->n + 3) & ~3) + ErrCfg::CHUNK - 1) / ErrCfg::CHUNK;
     s->dense_grid_y = (s->rows() + kErrTileRows - 1) / kErrTileRows;
     s->dense_blocks = s->dense_grid_x * s->dense_grid_y;
-    s->part_sum.alloc(std::max(s->n_parts, s->dense_blocks));
-    s->part_cnt.alloc(std::max(s->n_parts, s->dense_blocks));
+    const int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;   // fused checks: one partial per workgroup
+    s->part_sum.alloc(std::max({s->n_parts, s->dense_blocks, stage_blocks}));
+    s->part_cnt.alloc(std::max({s->n_parts, s->dense_blocks, stage_blocks}));
     // Can the MAE be reduced from the encoded block instead of gathering the edge list?  Only if
     // the list is exactly the set of measured cells the dense pass would visit -- checked with an
     // order-independent fingerprint BEFORE anything is uploaded: when it holds (it does for
@@ -987,6 +1045,7 @@ int topolow_session_set_positions(topolow_session* s, const double* positions, c
                              hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->held = -1;
+    s->pcheck.active = false;
   });
 }
 
@@ -1034,6 +1093,7 @@ int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double 
     s->k_host = k0;
     s->host_seen_stop = false;
     s->held = -1;
+    s->pcheck.active = false;
     s->began = true;
     RunState st;
     std::memset(&st, 0, sizeof st);
@@ -1066,47 +1126,43 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
       } else {
         const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_at(iter, s->k_host, s->dim);
         const SlabGeom g = slab_geom(s->n, stages);
+        const bool fuse_now = s->pcheck.active && g.n_stages == 1;
+        if (s->pcheck.active && !fuse_now) flush_pending_check(s);
         for (int slot = 0; slot < g.n_stages; ++slot) {
           const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
           int out = 0;   // a buffer that is neither the input nor the one a running check reads
           while (out == s->cur || out == s->held) ++out;
           TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[s->cur].p, s->pos[out].p, s->state.p, rg,
-                          iter + 1, s->k_host);
+                          iter + 1, s->k_host, nullptr, 0, fuse_now);
           s->cur = out;
         }
+        if (fuse_now) launch_check(s, s->pcheck, /*error_pass=*/false);
       }
       s->iters_enqueued = iter + 1;
       s->k_host *= (1.0 - s->cooling);  // reference :289
       ++done;
       if ((iter + 1) % s->check_freq == 0 || iter == s->n_iter - 1) {  // reference :294
-        const bool beside = s->schedule == TOPOLOW_SCHEDULE_SLAB && s->stream == s->own_stream &&
-                            !s->profiling && !s->serial_checks;
-        hipStream_t check_on = s->stream;
-        if (beside) {
-          // The check reads this iteration's positions while the next iteration's stages run.  Its
-          // verdict (stop / snapshot) is the same as in the serial order: the buffer it reads is
-          // not written until the next check has waited for it; stage kernels that start after a
-          // stop are no-ops and those already running write buffers nobody returns.
-          if (s->held >= 0) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_check_done, 0));
-          s->held = s->cur;
-          HIP_TRY(hipEventRecord(s->ev_iter_done, s->stream));
-          HIP_TRY(hipStreamWaitEvent(s->check_stream, s->ev_iter_done, 0));
-          check_on = s->check_stream;
-        } else if (s->held >= 0) {
-          HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_check_done, 0));
-          s->held = -1;
-        }
-        {
-          StreamScope on(s, check_on);
-          ProfScope prof(s, &s->prof_check);
-          TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[s->cur].p, s->state.p);
-          launch_controller(s, s->pos[s->cur].p, iter + 1, s->k_host);
-        }
-        if (beside) HIP_TRY(hipEventRecord(s->ev_check_done, check_on));
-        hipEvent_t e = take_event(s);
-        HIP_TRY(hipEventRecord(e, check_on));
-        s->pending.push_back(e);
-        poll_checks(s, 3);
+        topolow_session::PendingCheck pc;
+        pc.active = true;
+        pc.iter1 = iter + 1;
+        pc.k_after = s->k_host;
+        pc.buf = s->cur;
+        pc.beside = s->schedule == TOPOLOW_SCHEDULE_SLAB && s->stream == s->own_stream &&
+                    !s->profiling && !s->serial_checks;
+        // The check reads this iteration's positions while the next iteration's stages run.  Its
+        // verdict (stop / snapshot) is the same as in the serial order: the buffer it reads is
+        // not written until the next check has waited for it; stage kernels that start after a
+        // stop are no-ops and those already running write buffers nobody returns.
+        if (s->held >= 0) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_check_done, 0));
+        s->held = pc.beside ? s->cur : -1;
+        // one stage next iteration: its kernel reduces this check's MAE (the positions it reads ARE this
+        // check's positions) and the separate pass over the block is dropped
+        const bool fuse = s->fuse_checks && s->schedule == TOPOLOW_SCHEDULE_SLAB && iter + 1 < s->n_iter &&
+                          s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && s->rows() % 2 == 0 &&
+                          slab_geom(s->n, s->fixed_stages > 0 ? s->fixed_stages
+                                                              : slab_stages_at(iter + 1, s->k_host, s->dim)).n_stages == 1;
+        if (fuse) s->pcheck = pc;
+        else launch_check(s, pc, /*error_pass=*/true);
       }
       // the slab kernels flag non-finite results themselves; the in-place schedule is inspected at
       // the reference's cadence (:359-361), after that iteration's check
@@ -1122,6 +1178,7 @@ int topolow_session_sync(topolow_session* s, int32_t* iterations_run, int32_t* s
   if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
+    flush_pending_check(s);
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipStreamSynchronize(s->check_stream));
     poll_checks(s, 0);
@@ -1141,6 +1198,7 @@ int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* c
   int rc_nonfinite = TOPOLOW_OK;
   const int rc = guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
+    flush_pending_check(s);
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipStreamSynchronize(s->check_stream));
     poll_checks(s, 0);
@@ -1170,6 +1228,7 @@ int topolow_session_finish(topolow_session* s, double* positions_out, int32_t* c
 int topolow_session_check_trace(topolow_session* s, double* out, int32_t max_checks, int32_t* n_checks) {
   if (!s || (!out && max_checks > 0) || !n_checks) return TOPOLOW_ERR_BAD_ARGUMENT;
   (void)hipSetDevice(s->device);
+  try { flush_pending_check(s); } catch (const HipError&) { return TOPOLOW_ERR_HIP; }
   (void)hipStreamSynchronize(s->stream);
   (void)hipStreamSynchronize(s->check_stream);
   const int have = std::min(s->mailbox ? s->mailbox->n_checks : 0, s->trace_cap);
@@ -1190,6 +1249,7 @@ int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage
   if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
+    flush_pending_check(s);
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipStreamSynchronize(s->check_stream));
     auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double* ms, int64_t* cnt) {
@@ -1204,8 +1264,33 @@ int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage
       if (cnt) *cnt = (int64_t)v.size();
       v.clear();
     };
-    drain(s->prof_stage, stage_ms, stage_launches);
+    // stage launches: the plain ones plus those that also reduced a check's MAE (reported apart by
+    // topolow_session_profile_fused, which must be asked first)
+    double ms_a = 0.0, ms_b = 0.0;
+    int64_t n_a = 0, n_b = 0;
+    drain(s->prof_stage, &ms_a, &n_a);
+    drain(s->prof_stage_err, &ms_b, &n_b);
+    if (stage_ms) *stage_ms = ms_a + ms_b;
+    if (stage_launches) *stage_launches = n_a + n_b;
     drain(s->prof_check, check_ms, checks);
+  });
+}
+
+int topolow_session_profile_fused(topolow_session* s, double* fused_ms, int64_t* fused_launches, char* errbuf,
+                                  size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    flush_pending_check(s);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->check_stream));
+    double total = 0.0;
+    for (auto& pr : s->prof_stage_err) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) total += t;
+    }
+    if (fused_ms) *fused_ms = total;
+    if (fused_launches) *fused_launches = (int64_t)s->prof_stage_err.size();
   });
 }
 
