@@ -138,7 +138,9 @@ def run_single(args):
                 break
             with open(os.path.join(ROOT, "profiles", prof)) as fh:
                 for name, vals in json.load(fh).items():
-                    if "slab_stage_" in name and "<5, float" in name and "hbm_traffic_bytes_per_launch" in vals:
+                    # the plain instance (..., ANYTHR = false, ERR = false>), one-stage launches (profiles/README.md)
+                    if ("slab_stage_" in name and "<5, float" in name and "false, false> [one-stage launches]" in name
+                            and "hbm_traffic_bytes_per_launch" in vals):
                         traffic = vals["hbm_traffic_bytes_per_launch"]
                         traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                        "FETCH_SIZE x2 on gfx950; measured by the commit that added the file, not "

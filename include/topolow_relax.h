@@ -315,6 +315,9 @@ int64_t topolow_tilegs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_
  * phantom points of the padding columns and must be (1e18, 0, ..., 0) (1e150 in f64 sessions) in
  * BOTH ping-pong buffers; stages never write them. */
 int32_t topolow_session_position_rows(const topolow_session* s);
+/* Coordinates per point in such a buffer: ndim up to 10, 12 for ndim 11 and 12, 16 for ndim 13..16 (the
+ * kernels are instantiated for 1..10, 12 and 16 coordinates; extra coordinates must be, and stay, zero). */
+int32_t topolow_session_position_dim(const topolow_session* s);
 /* Launches stage `stage` of iteration `iter` (0-based) for the session's row block: reads
  * all n positions from d_pos_in, writes rows [row_begin,row_end) of d_pos_out. */
 int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_out,

@@ -145,8 +145,8 @@ def test_stage_kernel_awaits_its_lds_transfers_past_exactly_the_younger_loads():
     subprocess.run(["make", "-C", csrc, "asm"], check=True, capture_output=True)
     text = open(os.path.join(csrc, "topolow_relax.gfx950.s")).read()
     names = re.findall(r"^(_ZN7topolow22slab_stage_pipe_kernel\w+):", text, re.M)
-    # ndim 1..10 x {f32, f64} x {threshold, threshold-free} + the fp32 instances that also reduce the MAE
-    assert len(names) == 60
+    # coordinates x {f32, f64} x {threshold, threshold-free} + the fp32 instances that also reduce the MAE
+    assert len(names) == 72      # 12 coordinate counts (1..10, 12, 16)
     for name in names:
         start = text.index("\n" + name + ":")
         body = text[start:text.index(".Lfunc_end", start)].split("\n")

@@ -452,7 +452,46 @@ def test_slab_nonfinite_guard_and_messages():
         _native.optimize_layout_exact_arrays(*args, seed=1, schedule="slab")
     assert ei.value.code == _native.ERR_NONFINITE
     with pytest.raises(_native.NativeError) as ei:
-        _native.optimize_layout_exact_arrays(np.zeros((4, 11)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
+        _native.optimize_layout_exact_arrays(np.zeros((4, 17)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
+                                             [0] * 4, [], [], [], [], 5, 1.0, 0.1, 0.1, 1e-4, 5, 3, seed=1,
+                                             schedule="slab")
+    assert ei.value.code == _native.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("ndim", [11, 13, 16])
+def test_more_than_ten_dimensions_run_zero_padded(ndim):
+    """The reference accepts any ndim (src/optimization.cpp:129); the kernels are instantiated for 1..10, 12 and
+    16 coordinates, and 11 runs as 12, 13..15 as 16 with the extra coordinates held at exactly zero (a zero
+    coordinate adds 0 to every distance and receives 0 of every move).  Exact GS against the oracle replay, the
+    slab stages against the CPU model, the batch entry, est_distances."""
+    call, _ = _random_problem(90, ndim, 0.5, seed=ndim, thresholds=0.2, n_iter=12)
+    seed = 7
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="gs", precision="f64")
+    ref = _oracle_with_gs_order(call, seed)
+    assert got.positions.shape == (90, ndim)
+    assert np.abs(got.positions - ref.positions).max() <= 1e-12 and got.iterations == ref.iterations
+    batch, _secs = _native.optimize_layout_exact_batch([call, call], seeds=[seed, seed + 1])
+    assert np.abs(batch[0].positions - ref.positions).max() <= 1e-12
+    call2, _ = _random_problem(520, ndim, 0.7, seed=ndim + 1, thresholds=0.1, n_iter=6, k0=4.0)
+    import dataclasses
+    call_r = dataclasses.replace(call2, dissimilarity_matrix=_decode_rounded(call2))
+    s = _native.Session(520, ndim, precision="f64")
+    s.load_dense(call2.dissimilarity_matrix, call2.threshold_matrix, call2.degrees)
+    s.set_edges(call2.edge_i, call2.edge_j, call2.edge_dist, call2.edge_thresh)
+    s.set_positions(call2.initial_positions)
+    s.begin(6, call2.k0, call2.cooling_rate, call2.c_repulsion, 1e-12, 1000, 3, 42, 4)
+    s.run()
+    got = s.get_positions()
+    s.close()
+    want, _k = _model_run(call_r, 42, 4, 6, "f64")
+    assert got.shape == (520, ndim)
+    assert np.abs(got - want).max() <= 1e-9 * max(np.abs(want - call2.initial_positions).max(), 1.0)
+    f32 = _native.optimize_layout_exact_arrays(*layout_call_args(call2), seed=1, schedule="slab")
+    sm, cnt = orc.edge_error(f32.positions, call2.edge_i, call2.edge_j, call2.edge_dist, call2.edge_thresh)
+    assert f32.final_mae == pytest.approx(sm / cnt, rel=2e-5)
+    assert np.allclose(_native.est_distances(f32.positions), numpy_pdist(f32.positions), rtol=1e-14, atol=1e-14)
+    with pytest.raises(_native.NativeError) as ei:
+        _native.optimize_layout_exact_arrays(np.zeros((4, 17)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
                                              [0] * 4, [], [], [], [], 5, 1.0, 0.1, 0.1, 1e-4, 5, 3, seed=1,
                                              schedule="slab")
     assert ei.value.code == _native.ERR_UNSUPPORTED

@@ -18,14 +18,37 @@ os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(prefix + "_kt/*/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
+# per-kernel durations of the one-stage launches from the kernel trace (the stats file averages all launches)
+for f in glob.glob(prefix + "_kt/*/*_kernel_trace.csv"):
+    rows = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "slab_stage_" in r["Kernel_Name"]:
+            rows[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {}
+    for k, v in rows.items():
+        full = [x for x in v if x >= 52000]
+        out[k] = dict(launches=len(v), mean_us=sum(v) / len(v) / 1e3,
+                      one_stage_launches=len(full), one_stage_mean_us=(sum(full) / len(full) / 1e3) if full else None,
+                      one_stage_min_us=min(full) / 1e3 if full else None, one_stage_max_us=max(full) / 1e3 if full else None)
+    json.dump(out, open(f"profiles/{tag}_stage_kernel_trace.json", "w"), indent=1, sort_keys=True)
+    for k, v in out.items():
+        print("trace", k[-40:], v)
 summary = collections.defaultdict(dict)
 for sub in ("fetch", "write", "sq"):
     for f in glob.glob(f"{prefix}_{sub}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            agg[name]["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            names = [name]
+            # the stage kernel is launched with 16, 2 or 1 stages per iteration (same grid, different slab
+            # width): the one-stage launches -- the full 4 N^2-byte sweeps -- are those that take >= 52 us at
+            # config 3 (two-stage launches take ~40 us, sixteen-stage ones ~9 us)
+            if "slab_stage_" in name and dur >= 52000:
+                names.append(name + " [one-stage launches]")
+            for nm in names:
+                agg[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                agg[nm]["_dur_ns"].append(dur)
         for k, v in agg.items():
             for c, x in v.items():
                 if c == "_dur_ns":

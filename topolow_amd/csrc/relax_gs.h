@@ -707,7 +707,7 @@ class GsBatch : public GsBatchBase {
            hi = 0, hj = 0, ht = 0, best;
   };
   const GsProblem* pbs = nullptr;
-  int count = 0, dim = 0, n_max = 0;
+  int count = 0, dim = 0, udim = 0, n_max = 0;   // dim: coordinates the kernel carries (11 -> 12, 13..15 -> 16, zero-padded)
   size_t lds_max = 0, o_out = 0, o_prob = 0;
   bool sparse = false;
   std::vector<Off> off;
@@ -724,7 +724,8 @@ class GsBatch : public GsBatchBase {
   void stage(const GsProblem* pbs_, int count_) override {
     pbs = pbs_;
     count = count_;
-    dim = pbs[0].dim;
+    udim = pbs[0].dim;
+    dim = udim <= 10 ? udim : (udim <= 12 ? 12 : 16);
     lds_max = 0;
     n_max = 0;
     // one kernel instance per launch: the LDS-resident table is used when EVERY problem of the
@@ -736,7 +737,8 @@ class GsBatch : public GsBatchBase {
       const bool want_sparse = sparse;
       gs_parallel_for(count, [&](int b) {
         const GsProblem& p = pbs[b];
-        if (p.dim != dim) throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "batch must share ndim"};
+        if (p.dim != udim) throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "batch must share ndim"};
+        if (p.dim < 1 || p.dim > 16) throw GsHipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 16"};
         if (p.n < 2) throw GsHipError{TOPOLOW_ERR_TOO_FEW_POINTS, "Need at least 2 points for embedding"};
         if ((p.D == nullptr) != (p.T == nullptr))
           throw GsHipError{TOPOLOW_ERR_BAD_ARGUMENT, "dissimilarity and threshold matrices come together"};
@@ -801,7 +803,7 @@ class GsBatch : public GsBatchBase {
       double* g = A.host<double>(o.gplus);
       for (int i = 0; i < p.n; ++i) {
         g[i] = (double)p.degrees[i] + 1.0;   // reference :137-140
-        for (int d = 0; d < dim; ++d) pos[(size_t)i * dim + d] = (real)p.initial_positions[i + (size_t)d * p.n];
+        for (int d = 0; d < udim; ++d) pos[(size_t)i * dim + d] = (real)p.initial_positions[i + (size_t)d * p.n];
       }
       auto code_of = [](int c) { return (int8_t)(c == 0 ? 0 : (c == 1 ? 1 : -1)); };  // else-branch = "<"
       // edge codes keep "neither 0, 1 nor -1" apart: such a pair moves like "<" (:236-242) but never
@@ -895,9 +897,9 @@ class GsBatch : public GsBatchBase {
     switch (dim) {
 #define GS_CASE(D) case D: gs_launch<D, real>(d_problems, count, threads, lds_max, sparse, st); break;
       GS_CASE(1) GS_CASE(2) GS_CASE(3) GS_CASE(4) GS_CASE(5) GS_CASE(6) GS_CASE(7) GS_CASE(8)
-      GS_CASE(9) GS_CASE(10)
+      GS_CASE(9) GS_CASE(10) GS_CASE(12) GS_CASE(16)
 #undef GS_CASE
-      default: throw GsHipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 10"};
+      default: throw GsHipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 16"};
     }
   }
 
@@ -916,7 +918,7 @@ class GsBatch : public GsBatchBase {
       }
       const real* pos = A.host<real>(off[b].pos);
       for (int i = 0; i < p.n; ++i)
-        for (int d = 0; d < dim; ++d) res[b].positions[i + (size_t)d * p.n] = (double)pos[(size_t)i * dim + d];
+        for (int d = 0; d < udim; ++d) res[b].positions[i + (size_t)d * p.n] = (double)pos[(size_t)i * dim + d];
       res[b].converged = o.converged; res[b].iterations = o.iterations; res[b].iters_run = o.iters_run;
       res[b].n_checks = o.n_checks; res[b].final_mae = o.final_mae; res[b].final_k = o.final_k;
       res[b].nonfinite_iter = o.nonfinite_iter;

@@ -156,7 +156,7 @@ __device__ __forceinline__ void load_points(const real* lds_pos, int c4, real (&
 //   ks = 2k / (4 g_i + k), cg = (c_rep / 2) / g_i   (row constants, scalar registers)
 //   THR = false: the row holds no ">" / "<" targets (flag computed when the matrix is encoded),
 //   so a pair springs exactly when it is measured (target < +Inf).
-template <int DIM, typename real, bool THR, bool ERR = false>
+template <int DIM, typename real, bool THR, bool ERR = false, bool CNT = false>
 __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&pi)[DIM],
                                            uint32_t w, real ks, real cg, real (&acc)[DIM],
                                            float* err = nullptr, unsigned* cnt_wave = nullptr) {
@@ -190,8 +190,10 @@ __device__ __forceinline__ void pair_accum(const real (&pc)[DIM], const real (&p
   if constexpr (ERR) {
     // the convergence MAE of the positions this stage reads: a pair contributes exactly when its spring is
     // active (reference src/optimization.cpp:68-76 and :230-243 are the same three cases)
+    // CNT = false: the block holds no threshold target, every measured pair contributes whatever the
+    // positions are, and the host knows their number
     *err += spring ? (float)fabs(t - r) : 0.0f;
-    *cnt_wave += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(spring));
+    if constexpr (CNT) *cnt_wave += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(spring));
   }
 }
 
@@ -300,15 +302,15 @@ struct PipeRows {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       if (ANYTHR && thr) {
-        pair_accum<DIM, real, true, ERR>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r], &err, &cnt_wave);
-        pair_accum<DIM, real, true, ERR>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r], &err, &cnt_wave);
-        pair_accum<DIM, real, true, ERR>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r], &err, &cnt_wave);
-        pair_accum<DIM, real, true, ERR>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, true, ERR, ANYTHR>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, true, ERR, ANYTHR>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, true, ERR, ANYTHR>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, true, ERR, ANYTHR>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r], &err, &cnt_wave);
       } else {
-        pair_accum<DIM, real, false, ERR>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r], &err, &cnt_wave);
-        pair_accum<DIM, real, false, ERR>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r], &err, &cnt_wave);
-        pair_accum<DIM, real, false, ERR>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r], &err, &cnt_wave);
-        pair_accum<DIM, real, false, ERR>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, false, ERR, ANYTHR>(pc[0], pi[r], w[r].x, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, false, ERR, ANYTHR>(pc[1], pi[r], w[r].y, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, false, ERR, ANYTHR>(pc[2], pi[r], w[r].z, ks[r], cg[r], acc[r], &err, &cnt_wave);
+        pair_accum<DIM, real, false, ERR, ANYTHR>(pc[3], pi[r], w[r].w, ks[r], cg[r], acc[r], &err, &cnt_wave);
       }
     }
   }
@@ -324,7 +326,7 @@ struct PipeRows {
 // generic form (bit-identical results).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-template <int DIM, bool THR, bool ERR = false>
+template <int DIM, bool THR, bool ERR = false, bool CNT = false>
 __device__ __forceinline__ void pair_accum_rows2(const float (&pc)[DIM], const f32x2_t (&pi2)[DIM],
                                                  uint32_t w0, uint32_t w1, f32x2_t ks2, f32x2_t cg2,
                                                  f32x2_t (&acc2)[DIM], f32x2_t* err2 = nullptr,
@@ -359,8 +361,9 @@ __device__ __forceinline__ void pair_accum_rows2(const float (&pc)[DIM], const f
   if constexpr (ERR) {   // see pair_accum
     const f32x2_t a = {sp0 ? fabsf(e.x) : 0.0f, sp1 ? fabsf(e.y) : 0.0f};
     *err2 += a;
-    *cnt_wave += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sp0)) +
-                 (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sp1));
+    if constexpr (CNT)
+      *cnt_wave += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sp0)) +
+                   (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sp1));
   }
 }
 
@@ -384,15 +387,15 @@ struct PipeRows<DIM, float, 2, ANYTHR, true> {
   template <bool ERR>
   __device__ __forceinline__ void group(const float (&pc)[4][DIM], const uint4 (&w)[2]) {
     if (ANYTHR && thr) {
-      pair_accum_rows2<DIM, true, ERR>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2, &err2, &cnt_wave);
-      pair_accum_rows2<DIM, true, ERR>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2, &err2, &cnt_wave);
-      pair_accum_rows2<DIM, true, ERR>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2, &err2, &cnt_wave);
-      pair_accum_rows2<DIM, true, ERR>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, true, ERR, ANYTHR>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, true, ERR, ANYTHR>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, true, ERR, ANYTHR>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, true, ERR, ANYTHR>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2, &err2, &cnt_wave);
     } else {
-      pair_accum_rows2<DIM, false, ERR>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2, &err2, &cnt_wave);
-      pair_accum_rows2<DIM, false, ERR>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2, &err2, &cnt_wave);
-      pair_accum_rows2<DIM, false, ERR>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2, &err2, &cnt_wave);
-      pair_accum_rows2<DIM, false, ERR>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, false, ERR, ANYTHR>(pc[0], pi2, w[0].x, w[1].x, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, false, ERR, ANYTHR>(pc[1], pi2, w[0].y, w[1].y, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, false, ERR, ANYTHR>(pc[2], pi2, w[0].z, w[1].z, ks2, cg2, acc2, &err2, &cnt_wave);
+      pair_accum_rows2<DIM, false, ERR, ANYTHR>(pc[3], pi2, w[0].w, w[1].w, ks2, cg2, acc2, &err2, &cnt_wave);
     }
   }
   __device__ __forceinline__ double take_err() {
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
     const float* __restrict__ gplus, const unsigned char* __restrict__ rowflags, RunState* st,
     SlabRanges rg, int iter1, double k, double c_rep, int falling_priority,
     real* const* __restrict__ push, int n_push, double* __restrict__ part_sum,
-    unsigned long long* __restrict__ part_cnt) {
+    unsigned long long* __restrict__ part_cnt, unsigned long long fixed_cnt) {
   if (st != nullptr && st->stopped) return;
   TL_WG_STAMP(0);
   using G = PipeGeom<DIM, real, CFG::CHUNK>;
@@ -554,7 +557,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
       unsigned long long tc = 0;
       for (int q = 0; q < CFG::WAVES; ++q) { ts += red_s[q]; tc += red_c[q]; }
       part_sum[blockIdx.x] = ts;
-      part_cnt[blockIdx.x] = tc;
+      // threshold-free block: the number of contributing ordered pairs is the host's (2 x measured pairs)
+      part_cnt[blockIdx.x] = ANYTHR ? tc : (blockIdx.x == 0 ? fixed_cnt : 0ull);
     }
   }
 

@@ -35,7 +35,10 @@ using namespace topolow;
 
 namespace {
 
-constexpr int kMaxDim = 10;
+constexpr int kMaxDim = 16;
+// kernels are instantiated for 1..10, 12 and 16 coordinates; 11 runs as 12 and 13..15 as 16 with the extra
+// coordinates held at exactly zero (a zero coordinate adds 0 to every distance and receives 0 of every move)
+constexpr int kernel_dim(int ndim) { return ndim <= 10 ? ndim : (ndim <= 12 ? 12 : 16); }
 constexpr int kDefaultGsMaxN = 1024;
 
 struct HipError {
@@ -188,7 +191,7 @@ bool edges_are_the_matrix(const double* D, const int32_t* T, int n, const int32_
 // Session (slab path)
 // =========================================================================================
 struct topolow_session {
-  int n = 0, dim = 0, row_begin = 0, row_end = 0, ld = 0;
+  int n = 0, dim = 0, udim = 0, row_begin = 0, row_end = 0, ld = 0;   // dim: coordinates the kernels carry, udim: the caller's ndim
   int precision = TOPOLOW_PRECISION_F32;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -297,7 +300,9 @@ namespace {
     case 8: FN<8>(__VA_ARGS__); break;                \
     case 9: FN<9>(__VA_ARGS__); break;                \
     case 10: FN<10>(__VA_ARGS__); break;              \
-    default: throw HipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 10"}; \
+    case 12: FN<12>(__VA_ARGS__); break;              \
+    case 16: FN<16>(__VA_ARGS__); break;              \
+    default: throw HipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 16"}; \
   }
 
 struct ProfScope {
@@ -382,12 +387,12 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), 0, s->stream, s->enc.p, s->ld,
                        s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
                        s->rowflags.p, st, rg, iter1, k, s->c_rep, falling, (real* const*)push, n_push,
-                       s->part_sum.p, s->part_cnt.p);
+                       s->part_sum.p, s->part_cnt.p, (unsigned long long)(2ll * s->n_edges));
   };
   if constexpr (sizeof(real) == 4) {
     if (err) {   // the launch also reduces the convergence MAE of the positions it reads (one-stage iterations)
       if (s->any_threshold) {
-        constexpr int kThrWavesE = DIM >= 9 ? 3 : (DIM >= 5 ? 4 : 5);   // the error sums cost registers: 4 waves from ndim 5
+        constexpr int kThrWavesE = DIM >= 16 ? 1 : (DIM >= 12 ? 2 : (DIM >= 9 ? 3 : (DIM >= 5 ? 4 : 5)));   // the error sums cost registers: 4 waves from ndim 5
         using CfgThrE = StageCfg<CFG::THREADS, CFG::RPW, CFG::CHUNK, CFG::PRIO,
                                  CFG::MINWAVES < kThrWavesE ? CFG::MINWAVES : kThrWavesE>;
         launch(&slab_stage_pipe_kernel<DIM, real, CfgThrE, true, true>, 1);
@@ -402,7 +407,7 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
     // ndim 7 on it would spill inside the pair loop at a 5-wave budget (9x slower at ndim 10), so
     // it is built for 4 waves per SIMD there and for 3 from ndim 9 (tests/test_capi.py checks that no
     // instantiation uses scratch).
-    constexpr int kThrWaves = sizeof(real) == 4 ? (DIM >= 9 ? 3 : (DIM >= 7 ? 4 : 5)) : 1;
+    constexpr int kThrWaves = sizeof(real) == 4 ? (DIM >= 16 ? 1 : (DIM >= 12 ? 2 : (DIM >= 9 ? 3 : (DIM >= 7 ? 4 : 5)))) : 1;
     using CfgThr = StageCfg<CFG::THREADS, CFG::RPW, CFG::CHUNK, CFG::PRIO,
                             CFG::MINWAVES < kThrWaves ? CFG::MINWAVES : kThrWaves>;
     launch(&slab_stage_pipe_kernel<DIM, real, CfgThr, true>, 1);
@@ -429,7 +434,10 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
       default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
     }
 #else
-    launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push, err);
+    // register budget: 5 waves per SIMD up to ndim 10 (CfgProd), 3 at 12 coordinates, 2 at 16
+    using CfgDim = StageCfg<CfgProd::THREADS, CfgProd::RPW, CfgProd::CHUNK, CfgProd::PRIO,
+                            DIM <= 10 ? CfgProd::MINWAVES : (DIM <= 12 ? 3 : 2)>;
+    launch_stage_pipe<DIM, float, CfgDim>(s, pin, pout, st, rg, iter1, k, push, n_push, err);
 #endif
   }
   HIP_TRY(hipGetLastError());
@@ -500,7 +508,7 @@ void upload_positions(topolow_session* s, const double* host_colmajor, void* dst
     std::vector<double> tmp(nv, 0.0);
     for (int i = 0; i < s->n; ++i) {
       const int o = s->perm.empty() ? i : s->perm[i];
-      for (int d = 0; d < s->dim; ++d) tmp[(size_t)i * s->dim + d] = host_colmajor[o + (size_t)d * s->n];
+      for (int d = 0; d < s->udim; ++d) tmp[(size_t)i * s->dim + d] = host_colmajor[o + (size_t)d * s->n];
     }
     for (int i = s->n; i < s->pos_rows(); ++i) tmp[(size_t)i * s->dim] = kFarF64;
     HIP_TRY(hipMemcpyAsync(dst, tmp.data(), nv * 8, hipMemcpyHostToDevice, s->stream));
@@ -509,7 +517,7 @@ void upload_positions(topolow_session* s, const double* host_colmajor, void* dst
     std::vector<float> tmp(nv, 0.0f);
     for (int i = 0; i < s->n; ++i) {
       const int o = s->perm.empty() ? i : s->perm[i];
-      for (int d = 0; d < s->dim; ++d)
+      for (int d = 0; d < s->udim; ++d)
         tmp[(size_t)i * s->dim + d] = (float)host_colmajor[o + (size_t)d * s->n];
     }
     for (int i = s->n; i < s->pos_rows(); ++i) tmp[(size_t)i * s->dim] = kFarF32;
@@ -526,7 +534,7 @@ void download_positions(topolow_session* s, const void* src, double* host_colmaj
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (int i = 0; i < s->n; ++i) {
       const int o = s->perm.empty() ? i : s->perm[i];
-      for (int d = 0; d < s->dim; ++d) host_colmajor[o + (size_t)d * s->n] = tmp[(size_t)i * s->dim + d];
+      for (int d = 0; d < s->udim; ++d) host_colmajor[o + (size_t)d * s->n] = tmp[(size_t)i * s->dim + d];
     }
   } else {
     std::vector<float> tmp(nv);
@@ -534,7 +542,7 @@ void download_positions(topolow_session* s, const void* src, double* host_colmaj
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (int i = 0; i < s->n; ++i) {
       const int o = s->perm.empty() ? i : s->perm[i];
-      for (int d = 0; d < s->dim; ++d)
+      for (int d = 0; d < s->udim; ++d)
         host_colmajor[o + (size_t)d * s->n] = (double)tmp[(size_t)i * s->dim + d];
     }
   }
@@ -785,7 +793,8 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     s = new topolow_session();
     s->device = dev;
     s->n = n;
-    s->dim = ndim;
+    s->dim = kernel_dim(ndim);
+    s->udim = ndim;
     s->row_begin = row_begin;
     s->row_end = row_end;
     s->ld = (n + kEncLdAlign - 1) & ~(kEncLdAlign - 1);
@@ -801,7 +810,7 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     const char* fuse = getenv("TOPOLOW_FUSE_CHECKS");
     s->fuse_checks = !(fuse != nullptr && fuse[0] == '0');
     s->enc.alloc((size_t)((s->rows() + kEncRowAlign - 1) / kEncRowAlign * kEncRowAlign) * s->ld);
-    const size_t pos_bytes = (size_t)s->pos_rows() * ndim * s->real_size();
+    const size_t pos_bytes = (size_t)s->pos_rows() * s->dim * s->real_size();
     for (auto& b : s->pos) b.alloc(pos_bytes);
     s->best.alloc(pos_bytes);
     s->state.alloc(1);
@@ -1159,6 +1168,7 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         // check's positions) and the separate pass over the block is dropped
         const bool fuse = s->fuse_checks && s->schedule == TOPOLOW_SCHEDULE_SLAB && iter + 1 < s->n_iter &&
                           s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && s->rows() % 2 == 0 &&
+                          s->row_begin == 0 && s->row_end == s->n &&   // (the host's pair count is the whole problem's)
                           slab_geom(s->n, s->fixed_stages > 0 ? s->fixed_stages
                                                               : slab_stages_at(iter + 1, s->k_host, s->dim)).n_stages == 1;
         if (fuse) s->pcheck = pc;
@@ -1318,6 +1328,7 @@ int64_t topolow_tilegs_pair_order(int32_t n, uint64_t seed, int32_t iter, int32_
 }
 
 int32_t topolow_session_position_rows(const topolow_session* s) { return s ? s->pos_rows() : 0; }
+int32_t topolow_session_position_dim(const topolow_session* s) { return s ? s->dim : 0; }
 
 int32_t topolow_session_uses_dense_mae(const topolow_session* s) {
   return s && s->dense_mae ? 1 : 0;
@@ -1329,7 +1340,7 @@ int64_t topolow_session_stage_launches(const topolow_session* s) {
 
 int64_t topolow_session_bytes_per_iteration(const topolow_session* s) {
   if (!s) return 0;
-  return 4ll * s->rows() * s->n + 8ll * s->n * s->dim + 4ll * s->n;
+  return 4ll * s->rows() * s->n + 8ll * s->n * s->udim + 4ll * s->n;
 }
 
 int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_out,
@@ -1900,7 +1911,7 @@ int topolow_optimize_layout_exact(
 
   // exact GS: one workgroup while the problem fits its LDS, the tile schedule beyond that
   const bool gs_fits_lds =
-      gs_lds_bytes(n, ndim, (opt.precision == TOPOLOW_PRECISION_F32) ? 4 : 8) <= 150 * 1024 && n <= 2048;
+      gs_lds_bytes(n, kernel_dim(ndim), (opt.precision == TOPOLOW_PRECISION_F32) ? 4 : 8) <= 150 * 1024 && n <= 2048;
   const bool tile_gs = schedule == TOPOLOW_SCHEDULE_GS && !gs_fits_lds;
   if (schedule == TOPOLOW_SCHEDULE_GS && !tile_gs) {
     int precision = opt.precision == TOPOLOW_PRECISION_AUTO ? TOPOLOW_PRECISION_F64 : opt.precision;
