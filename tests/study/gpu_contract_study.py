@@ -1,6 +1,10 @@
-"""Study (not a test): final-MAE statistics of the production path (relabelled slab schedule through the one-shot
-entry) for comparison with the oracle distributions; the stage-count floor comes from TOPOLOW_MIN_STAGES.
-  python tests/study/gpu_minstage_study.py <out.json> <problem|cfg3> <seeds>"""
+"""Study (not a test): final-MAE statistics of the production path (slab schedule with random labels through the
+one-shot entry) against the oracle distributions of tests/golden -- the numbers behind DESIGN.md section 2b and the
+bands of tests/test_gpu_contract.py.
+  python tests/study/gpu_contract_study.py <out.json> <problem|cfg3> <seeds>
+Round 2 ran it (and variants of it, with knobs that are no longer in the library) to decide: index-contiguous against
+random labels, the stage floor of the unfolding phase (4 / 16 / 32 / 64 stages for 12-100 iterations), the stage
+floor afterwards (4 / 2 / 1)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -19,7 +23,7 @@ if name == "cfg3":
 else:
     d = pp.oracle_distribution(name); m, sd = d["mean_final_mae"], d["sd_final_mae"]
 band = max(3 * sd, 0.01 * m)
-print(f"{name} min_stages={os.environ.get('TOPOLOW_MIN_STAGES', '4')}: mean {fm.mean():.5f} sd {fm.std(ddof=1):.5f} "
+print(f"{name}: mean {fm.mean():.5f} sd {fm.std(ddof=1):.5f} "
       f"[{fm.min():.4f}, {fm.max():.4f}] | oracle {m:.5f} sd {sd:.5f} band {band:.5f} -> diff {fm.mean() - m:+.5f} "
       f"({100 * (fm.mean() / m - 1):+.2f} %) {'OK' if abs(fm.mean() - m) <= band else 'OUT'}; iters "
       f"{np.mean([r.iterations for r in runs]):.0f}; device s/run {np.mean([r.info['device_seconds'] for r in runs]):.4f} "

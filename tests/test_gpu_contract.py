@@ -16,7 +16,7 @@ minutes each).  Further bands, stated where they are asserted:
     deviation seen in the 32-seed studies is 8.3 %);
   * recovered distances: a run's distances among the first 48 points differ from the oracle's seed-mean
     by no more than 1.5 x the largest gap an oracle seed shows + 0.5 %.
-Measured means behind these tests: tests/study/gpu_relabel_study.py, DESIGN.md section 2.
+Measured means behind these tests: tests/study/gpu_contract_study.py, DESIGN.md section 2.
 """
 import numpy as np
 import pytest

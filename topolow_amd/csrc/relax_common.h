@@ -166,7 +166,7 @@ TL_HD inline SlabRanges slab_ranges(const SlabGeom& g, uint64_t seed, int iter, 
 // k / S <= min(2.5, d): a factor 2 inside either bound.  No other floor: once k <= 2.5 (d >= 3) an iteration is
 // ONE sweep -- one 4 N^2-byte launch instead of four (config 3: 0.61 instead of 0.48 of HBM peak) -- and the
 // final-MAE statistics are those of 4 stages to 1e-4 (32 seeds on each pinned problem,
-// tests/study/gpu_minstage_study.py): what decides the result happens in the first iterations, see below.
+// tests/study/gpu_contract_study.py): what decides the result happens in the first iterations, see below.
 TL_HD inline int slab_stages_for_k(double k, int ndim) {
   const double per_stage = ndim < 3 ? (double)(ndim < 1 ? 1 : ndim) : 2.5;
   int s = 1;
@@ -176,7 +176,7 @@ TL_HD inline int slab_stages_for_k(double k, int ndim) {
 
 // While the layout unfolds from the reference's random-walk start (R/core.R:407-415) the moves are
 // large and which basin the embedding settles in is decided: the first kEarlyIters iterations run
-// at least kEarlyStages stages.  Measured on MI355X (tests/study/gpu_relabel_study.py, 32 seeds per
+// at least kEarlyStages stages.  Measured on MI355X (tests/study/gpu_contract_study.py, 32 seeds per
 // problem): with this floor and random labels the final-MAE distribution of the slab schedule sits
 // inside the reference-order oracle's  mean +- max(3 sd, 1 %)  on every pinned problem; what runs
 // after iteration 16 no longer moves the result (same seeds end within 1e-4 of each other).
