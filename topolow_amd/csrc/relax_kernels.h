@@ -540,14 +540,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
     if constexpr (ERR) err_d += R.take_err();   // fp32 partial of one chunk (<= 32 terms per lane) into f64
   }
   if constexpr (ERR) {
-    // rows past the block's end were clamped onto its last row: their pairs must not count twice
+    // a wave whose rows lie past the block's end works on clamped copies of the last row: it contributes
+    // nothing (the host fuses a check only into blocks of an even number of rows, so a wave's two rows are
+    // valid or invalid together)
     double s = 0.0;
     unsigned long long c = 0;
     if (row0 + RPW - 1 < row_end) { s = wave_sum<double>(err_d); c = R.cnt_wave; }
-    else {
-      // ragged last wave: recount is not possible pair by pair here, so such a launch is never ERR
-      // (the host only fuses when the row block is a multiple of RPW rows)
-    }
     double* red_s = reinterpret_cast<double*>(bufs);                       // the point buffers are free now
     unsigned long long* red_c = reinterpret_cast<unsigned long long*>(bufs + 64);
     if (lane == 0) { red_s[wave] = s; red_c[wave] = c; }
