@@ -1031,19 +1031,26 @@ __global__ __launch_bounds__(kThreads) void upper_fingerprint_kernel(
   }
 }
 
-// rowflags[i] = 1 when encoded row i holds a ">" target or a measured "<" target.
+// rowflags[i] = 1 when encoded row i holds a ">" target or a measured "<" target; *measured += the row's
+// measured cells (every word but the unmeasured one).
 __global__ __launch_bounds__(kThreads) void row_flags_kernel(const uint32_t* __restrict__ enc,
                                                              int rows, int ld,
-                                                             unsigned char* __restrict__ flags) {
+                                                             unsigned char* __restrict__ flags,
+                                                             unsigned long long* __restrict__ measured) {
   const int i = blockIdx.x;
   if (i >= rows) return;
   int any = 0;
+  unsigned cnt = 0;
   for (int c = threadIdx.x; c < ld; c += kThreads) {
     const uint32_t w = enc[enc_index(i, c, ld)];
     const uint32_t code = w & kCodeMask;
     any |= (code == 1u) | ((code == 2u) & (w != kInfWord));
+    cnt += w != kInfWord ? 1u : 0u;
   }
   any = __syncthreads_or(any);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
+  if ((threadIdx.x & 63) == 0 && cnt != 0) atomicAdd(measured, (unsigned long long)cnt);
   if (threadIdx.x == 0) flags[i] = any ? 1 : 0;
 }
 

@@ -111,6 +111,38 @@ inline void sharded_worker(ShardedRun& R, int r) {
   int cur = 0;
   double k = R.k0;
   int iter = 0;
+  // Position buffers rotate through three: a stage reads `cur` and writes (own rows, and the other blocks' copies)
+  // the next one, so the buffer a check measured is not written for two more stages.
+  // A check whose error pass is deferred into the next iteration's single sweep (slab_stage_pipe_kernel<ERR>):
+  // the sweep's barrier then also carries the blocks' (sum, count) slots, so the check costs no pass over the
+  // block and no barrier of its own.  Its controller runs behind that barrier and snapshots the buffer the sweep
+  // READ; other blocks may already be writing their next stage -- into the third buffer.  Decided from the
+  // schedule alone, hence identically in every thread.
+  bool pend = false;
+  int pend_iter1 = 0, pend_buf = 0;
+  double pend_k = 0.0;
+  auto can_fuse = [&](const topolow_session* s) {
+    return s->fuse_checks && s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && s->rows() % 2 == 0;
+  };
+  bool fusable = true;
+  for (topolow_session* s : R.ss) fusable = fusable && can_fuse(s);
+  auto separate_check = [&](int buf, int iter1, double k_after) -> bool {
+    for (int b : G.blocks) {
+      topolow_session* s = R.ss[b];
+      ProfScope prof(s, &s->prof_check);
+      TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[buf].p, s->state.p);
+      hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
+                         error_parts(s), s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, s->rank, s->state.p);
+      HIP_TRY(hipGetLastError());
+    }
+    if (!exchange()) return false;
+    for (int b : G.blocks) {
+      topolow_session* s = R.ss[b];
+      ProfScope prof(s, &s->prof_check);
+      launch_controller(s, s->pos[buf].p, iter1, k_after, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
+    }
+    return true;
+  };
   for (; iter < R.n_iter; ++iter) {
     if (seen != 0) break;
     if (R.warmup_iters > 0 && iter == R.warmup_iters) {   // measurement only: drain, meet, start the clock
@@ -123,34 +155,43 @@ inline void sharded_worker(ShardedRun& R, int r) {
       R.interrupted = R.interrupt_cb(R.interrupt_user) != 0;   // published at the next exchange
     const int stages = R.fixed_stages > 0 ? R.fixed_stages : slab_stages_at(iter, k, lead->dim);
     const SlabGeom geo = slab_geom(lead->n, stages);
+    const bool fuse_now = pend && geo.n_stages == 1;
+    if (pend && !fuse_now) { if (!separate_check(pend_buf, pend_iter1, pend_k)) return; pend = false; }
     for (int slot = 0; slot < geo.n_stages; ++slot) {
       const SlabRanges rg = slab_ranges(geo, lead->seed, iter, slot);
       for (int b : G.blocks) {
         topolow_session* s = R.ss[b];
-        TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[cur].p, s->pos[cur ^ 1].p, s->state.p, rg, iter + 1, k,
-                        s->push_tab[cur ^ 1].p, s->n_push);
+        TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[cur].p, s->pos[(cur + 1) % 3].p, s->state.p, rg, iter + 1, k,
+                        s->push_tab[(cur + 1) % 3].p, s->n_push, fuse_now);
+        if (fuse_now) {   // the sweep's per-workgroup partials -> this block's slot of every rank table
+          const int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
+          ProfScope prof(s, &s->prof_check);
+          hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
+                             stage_blocks, s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, s->rank, s->state.p);
+          HIP_TRY(hipGetLastError());
+        }
       }
       if (!exchange()) return;
-      cur ^= 1;
+      if (fuse_now) {
+        for (int b : G.blocks) {
+          topolow_session* s = R.ss[b];
+          ProfScope prof(s, &s->prof_check);
+          launch_controller(s, s->pos[pend_buf].p, pend_iter1, pend_k, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
+        }
+        pend = false;
+      }
+      cur = (cur + 1) % 3;
     }
     k *= (1.0 - R.cooling);   // reference :289
     if ((iter + 1) % R.check_freq == 0 || iter == R.n_iter - 1) {   // reference :294
-      for (int b : G.blocks) {
-        topolow_session* s = R.ss[b];
-        ProfScope prof(s, &s->prof_check);
-        TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[cur].p, s->state.p);
-        hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
-                           error_parts(s), s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, s->rank, s->state.p);
-        HIP_TRY(hipGetLastError());
-      }
-      if (!exchange()) return;
-      for (int b : G.blocks) {
-        topolow_session* s = R.ss[b];
-        ProfScope prof(s, &s->prof_check);
-        launch_controller(s, s->pos[cur].p, iter + 1, k, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
-      }
+      const bool fuse = fusable && iter + 1 < R.n_iter &&
+                        slab_geom(lead->n, R.fixed_stages > 0 ? R.fixed_stages
+                                                              : slab_stages_at(iter + 1, k, lead->dim)).n_stages == 1;
+      if (fuse) { pend = true; pend_iter1 = iter + 1; pend_k = k; pend_buf = cur; }
+      else if (!separate_check(cur, iter + 1, k)) return;
     }
   }
+  if (pend) { if (!separate_check(pend_buf, pend_iter1, pend_k)) return; pend = false; }   // the loop ended early
   for (int b : G.blocks) R.ss[b]->cur = cur;
   if (r == 0) { R.iters_enqueued = iter; R.exchanges = g; }
   HIP_TRY(hipStreamSynchronize(G.stream));
@@ -177,7 +218,7 @@ inline void sharded_wire(std::vector<topolow_session*>& ss) {
     s->n_ranks = P;
     s->rank = a;
     s->n_push = P - 1;
-    for (int b2 = 0; b2 < 2; ++b2) {
+    for (int b2 = 0; b2 < 3; ++b2) {
       std::vector<void*> tab;
       for (int q = 0; q < P; ++q) if (q != a) tab.push_back((void*)ss[q]->pos[b2].p);
       s->push_tab[b2].alloc(tab.size());

@@ -220,6 +220,7 @@ struct topolow_session {
   DevBuf<float> gplus;
   DevBuf<unsigned char> rowflags;
   bool any_threshold = true;   // does any row of the block hold a ">" / "<" target?
+  unsigned long long block_cells = 0;   // measured (ordered) cells of the block: 2 x the measured pairs of a whole problem
   int schedule = TOPOLOW_SCHEDULE_SLAB;   // SLAB, or GS = exact tile Gauss-Seidel (relax_tilegs.h)
   DevBuf<int> bperm;
   DevBuf<unsigned char> pos[3];   // stage ping-pong + the buffer a running check reads
@@ -255,7 +256,7 @@ struct topolow_session {
   std::deque<hipEvent_t> pending;
   std::vector<hipEvent_t> event_pool;
   // row-sharded engine (topolow_sessions_run_sharded): this block's view of the other blocks
-  DevBuf<void*> push_tab[2];           // [b]: the other blocks' position buffer b (device pointers)
+  DevBuf<void*> push_tab[3];           // [b]: the other blocks' position buffer b (device pointers)
   int n_push = 0;
   DevBuf<double> rank_sum;             // one (sum, count) slot per block, written by every block
   DevBuf<unsigned long long> rank_cnt;
@@ -387,7 +388,7 @@ void launch_stage_pipe(topolow_session* s, const void* pin, void* pout, RunState
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(CFG::THREADS), 0, s->stream, s->enc.p, s->ld,
                        s->row_begin, s->row_end, s->n, (const real*)pin, (real*)pout, s->gplus.p,
                        s->rowflags.p, st, rg, iter1, k, s->c_rep, falling, (real* const*)push, n_push,
-                       s->part_sum.p, s->part_cnt.p, (unsigned long long)(2ll * s->n_edges));
+                       s->part_sum.p, s->part_cnt.p, s->block_cells);
   };
   if constexpr (sizeof(real) == 4) {
     if (err) {   // the launch also reduces the convergence MAE of the positions it reads (one-stage iterations)
@@ -550,10 +551,14 @@ void download_positions(topolow_session* s, const void* src, double* host_colmaj
 
 void compute_row_flags(topolow_session* s) {
   s->rowflags.alloc(s->rows());
+  DevBuf<unsigned long long> measured;
+  measured.alloc(1);
+  HIP_TRY(hipMemsetAsync(measured.p, 0, sizeof(unsigned long long), s->stream));
   hipLaunchKernelGGL(row_flags_kernel, dim3(s->rows()), dim3(kThreads), 0, s->stream, s->enc.p,
-                     s->rows(), s->ld, s->rowflags.p);
+                     s->rows(), s->ld, s->rowflags.p, measured.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(&s->block_cells, measured.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
   std::vector<unsigned char> h(s->rows());
   HIP_TRY(hipMemcpy(h.data(), s->rowflags.p, h.size(), hipMemcpyDeviceToHost));
   s->any_threshold = false;
@@ -1168,7 +1173,6 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         // check's positions) and the separate pass over the block is dropped
         const bool fuse = s->fuse_checks && s->schedule == TOPOLOW_SCHEDULE_SLAB && iter + 1 < s->n_iter &&
                           s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && s->rows() % 2 == 0 &&
-                          s->row_begin == 0 && s->row_end == s->n &&   // (the host's pair count is the whole problem's)
                           slab_geom(s->n, s->fixed_stages > 0 ? s->fixed_stages
                                                               : slab_stages_at(iter + 1, s->k_host, s->dim)).n_stages == 1;
         if (fuse) s->pcheck = pc;
