@@ -81,6 +81,11 @@ def _syn1500():
     return call, prob.dissimilarity
 
 
+def _syn_lowdim(n, dim, missing, seed):
+    call, prob = random_problem(n, dim, missing, seed=seed, n_iter=1000, k0=5.0, cool=0.01, c_rep=0.01)
+    return call, prob.dissimilarity
+
+
 def _cfg3gen(n, censored=0.0, eps=1e-4, **kw):
     call, prob = cfg3_generator(n, censored, eps=eps, **kw)
     return call, (prob.dissimilarity if censored == 0 else None)
@@ -103,6 +108,12 @@ PROBLEMS = {
     # a soft, slowly cooling spring: after the unfolding phase every iteration is ONE Jacobi sweep (k <= 2.5)
     "cfg3gen_1500_lowk": dict(fn=functools.partial(_cfg3gen, 1500, 0.0, 1e-4, k0=2.0, cool=0.004, c_rep=0.01),
                               doc="cfg3_generator(1500, k0=2.0, cool=0.004)"),
+    # low dimensions: the stage policy is k / S <= min(2.5, ndim) (a Jacobi stage is stable for k / S < 2 ndim)
+    "syn1500_ndim2": dict(fn=lambda: _syn_lowdim(1500, 2, 0.7, 11), doc="random_problem(1500, 2, 0.7, seed=11, "
+                          "n_iter=1000, k0=5, cool=0.01, c_rep=0.01)"),
+    "syn2000_ndim3_sparse": dict(fn=lambda: _syn_lowdim(2000, 3, 0.9, 12), doc="random_problem(2000, 3, 0.9, seed=12, "
+                                 "n_iter=1000, k0=5, cool=0.01, c_rep=0.01): BASELINE config 4's shape (ndim 3, 90 % "
+                                 "missing) at a size the oracle finishes"),
     "h3n2_ndim4": dict(fn=lambda: (h3n2_call(4), None), doc="Smith-2004 H3N2 panel (tests/golden/"
                        "h3n2_distances.csv), ndim 4, published parameters, start positions default_rng(7)"),
     "h3n2_ndim5": dict(fn=lambda: (h3n2_call(5), None), doc="the same, ndim 5 (BASELINE config 2)"),
