@@ -350,6 +350,15 @@ int topolow_session_check_partial(topolow_session* s, const void* d_pos, double*
                                   size_t errlen);
 int topolow_session_controller_step(topolow_session* s, const double* d_total2, const void* d_pos,
                                     int32_t iter1, double k_after, char* errbuf, size_t errlen);
+/* The fused form of a check for one-stage iterations: the ONE stage of iteration `iter` (0-based), which
+ * also reduces this block's share of the convergence MAE of the positions it READS (d_pos_in: the previous
+ * iteration's result, i.e. the previous iteration's check) into the two doubles at d_out2 -- no separate
+ * pass over the block.  The caller all-reduces d_out2 and calls controller_step with d_pos_in and the
+ * previous iteration's number.  topolow_session_can_fuse_checks: 1 when the session supports it (fp32,
+ * MAE reduced from the block, even row count). */
+int32_t topolow_session_can_fuse_checks(const topolow_session* s);
+int topolow_session_stage_fused(topolow_session* s, const void* d_pos_in, void* d_pos_out, int32_t iter,
+                                double k, double* d_out2, char* errbuf, size_t errlen);
 /* First iteration (1-based) at which one of this block's rows became non-finite, 0 = none. Waits. */
 int topolow_session_first_nonfinite(topolow_session* s, int32_t* iteration);
 /* Partial edge error of this session's edge list on d_pos: (sum, count). Synchronous. */

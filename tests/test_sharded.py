@@ -56,6 +56,13 @@ class ModelBackend:
             self.bad = it + 1
         self.iters_run = max(self.iters_run, it + 1)
 
+    can_fuse_checks = True
+
+    def stage_fused(self, pos_in, pos_out, it, k):
+        total = self.check_partial(pos_in)       # the MAE of the positions the stage READS
+        self.stage(pos_in, pos_out, it, 0, 1, k)
+        return total
+
     def check_partial(self, pos):
         c = self.call
         sl = self.edges

@@ -158,6 +158,11 @@ def load() -> C.CDLL:
     lib.topolow_session_labels.argtypes = [C.c_void_p, ip]
     lib.topolow_session_check_partial.restype = C.c_int
     lib.topolow_session_check_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.topolow_session_can_fuse_checks.restype = C.c_int32
+    lib.topolow_session_can_fuse_checks.argtypes = [C.c_void_p]
+    lib.topolow_session_stage_fused.restype = C.c_int
+    lib.topolow_session_stage_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p,
+                                                C.c_char_p, C.c_size_t]
     lib.topolow_session_controller_step.restype = C.c_int
     lib.topolow_session_controller_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
                                                     C.c_char_p, C.c_size_t]
@@ -841,6 +846,16 @@ class Session:
         _check(self.lib.topolow_session_controller_step(self._h, C.c_void_p(d_total2), C.c_void_p(d_pos),
                                                         int(iter1), float(k_after), self._err,
                                                         len(self._err)), self._err)
+
+    @property
+    def can_fuse_checks(self) -> bool:
+        return bool(self.lib.topolow_session_can_fuse_checks(self._h))
+
+    def stage_fused(self, d_pos_in: int, d_pos_out: int, it: int, k: float, d_out2: int):
+        """The single stage of iteration `it`, also reducing this block's share of the MAE of d_pos_in."""
+        _check(self.lib.topolow_session_stage_fused(self._h, C.c_void_p(d_pos_in), C.c_void_p(d_pos_out), int(it),
+                                                    float(k), C.c_void_p(d_out2), self._err, len(self._err)),
+               self._err)
 
     def first_nonfinite(self) -> int:
         it = C.c_int32(0)

@@ -1365,6 +1365,30 @@ int topolow_session_stage(topolow_session* s, const void* d_pos_in, void* d_pos_
   });
 }
 
+int32_t topolow_session_can_fuse_checks(const topolow_session* s) {
+  return s && s->fuse_checks && s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && s->rows() % 2 == 0 ? 1 : 0;
+}
+
+int topolow_session_stage_fused(topolow_session* s, const void* d_pos_in, void* d_pos_out, int32_t iter,
+                                double k, double* d_out2, char* errbuf, size_t errlen) {
+  if (!s || !d_pos_in || !d_pos_out || !d_out2 || !s->began) return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (!topolow_session_can_fuse_checks(s)) {
+    set_err(errbuf, errlen, "this session cannot fuse checks (needs the fp32 block-based MAE and an even row count)");
+    return TOPOLOW_ERR_UNSUPPORTED;
+  }
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    const SlabGeom g = slab_geom(s->n, 1);
+    const SlabRanges rg = slab_ranges(g, s->seed, iter, 0);
+    TL_DISPATCH_DIM(s->dim, launch_stage, s, d_pos_in, d_pos_out, s->state.p, rg, iter + 1, k, nullptr, 0, true);
+    const int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
+    hipLaunchKernelGGL(reduce_total_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
+                       stage_blocks, d_out2, s->state.p);
+    HIP_TRY(hipGetLastError());
+    s->iters_enqueued = std::max(s->iters_enqueued, iter + 1);
+  });
+}
+
 int topolow_session_check_partial(topolow_session* s, const void* d_pos, double* d_out2, char* errbuf,
                                   size_t errlen) {
   if (!s || !d_pos || !d_out2 || !s->part_sum.p || !s->began) return TOPOLOW_ERR_BAD_ARGUMENT;

@@ -165,6 +165,15 @@ class HipBackend:
         self.session.check_partial(pos.data_ptr(), self._t2.data_ptr())
         return self._t2
 
+    @property
+    def can_fuse_checks(self):
+        return self.session.can_fuse_checks
+
+    def stage_fused(self, pos_in, pos_out, it, k):
+        """The single stage of iteration `it`, which also reduces the MAE of pos_in (the previous check's positions)."""
+        self.session.stage_fused(pos_in.data_ptr(), pos_out.data_ptr(), it, k, self._t2.data_ptr())
+        return self._t2
+
     def controller_step(self, total2, pos, iter1, k_after):
         self.session.controller_step(total2.data_ptr(), pos.data_ptr(), iter1, k_after)
 
@@ -214,9 +223,25 @@ def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, ini
     k = k0
     t_stage = t_gather = t_check = 0.0
     checks = 0
+    ndim = int(np.asarray(initial_positions).shape[1])
+    fusable = bool(getattr(backend, "can_fuse_checks", False)) and not timers
+    pending = None      # (iter1, k_after, buffer index): a check that rides on the next iteration's single stage
+
+    def n_slots_of(it_, k_):
+        st = slab_stages if slab_stages > 0 else _native.slab_stages_at(it_, k_, ndim)
+        return st, len(_native.slab_plan(n, st, seed, it_))
+
+    def separate_check(buf, iter1, k_after):
+        total = backend.check_partial(pos[buf])
+        coll.all_reduce_tensor(total)
+        backend.controller_step(total, pos[buf], iter1, k_after)
+
     for it in range(n_iter):
-        stages = slab_stages if slab_stages > 0 else _native.slab_stages_at(it, k, int(np.asarray(initial_positions).shape[1]))
-        n_slots = len(_native.slab_plan(n, stages, seed, it))
+        stages, n_slots = n_slots_of(it, k)
+        fuse_now = pending is not None and n_slots == 1
+        if pending is not None and not fuse_now:
+            separate_check(pending[2], pending[0], pending[1])
+            pending = None
         for slot in range(n_slots):
             if timers:   # breakdown pass: host-synchronised, so slower than the timed pass
                 backend.synchronize()
@@ -228,6 +253,14 @@ def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, ini
                 backend.synchronize()
                 t_stage += t1 - t0
                 t_gather += time.perf_counter() - t1
+            elif fuse_now:
+                # one sweep: the stage, the MAE of the positions it reads (= the pending check), the gather of the
+                # new slices, the all-reduce of the two MAE scalars, the controller -- all enqueued
+                total = backend.stage_fused(pos[cur], pos[cur ^ 1], it, k)
+                coll.all_gather_rows(pos[cur ^ 1], per, rank)
+                coll.all_reduce_tensor(total)
+                backend.controller_step(total, pos[pending[2]], pending[0], pending[1])
+                pending = None
             else:
                 backend.stage(pos[cur], pos[cur ^ 1], it, slot, stages, k)
                 coll.all_gather_rows(pos[cur ^ 1], per, rank)
@@ -235,15 +268,19 @@ def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, ini
         k *= (1.0 - cooling_rate)
         if (it + 1) % freq == 0 or it == n_iter - 1:
             t0 = time.perf_counter() if timers else 0.0
-            total = backend.check_partial(pos[cur])
-            coll.all_reduce_tensor(total)
-            backend.controller_step(total, pos[cur], it + 1, k)
+            if fusable and it + 1 < n_iter and n_slots_of(it + 1, k)[1] == 1:
+                pending = (it + 1, k, cur)
+            else:
+                separate_check(cur, it + 1, k)
             checks += 1
             if timers:
                 backend.synchronize()
                 t_check += time.perf_counter() - t0
             if checks % max(1, sync_every) == 0 and backend.poll()[0]:
                 break
+    if pending is not None:
+        separate_check(pending[2], pending[0], pending[1])
+        pending = None
     _stopped, iters_run = backend.poll()
     bad = int(coll.min_float(float(backend.first_nonfinite() or 0x7FFFFFFF)))
     if bad != 0x7FFFFFFF:
