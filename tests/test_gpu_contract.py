@@ -12,8 +12,8 @@ tests/golden/oracle_dist_<problem>.json (tests/golden/make_oracle_distributions.
 config 3 at full size from the oracle's 20 full-size records (tests/golden/cfg3_oracle_seed*.json, ~48 CPU
 minutes each).  Further bands, stated where they are asserted:
   * stop iteration: mean within max(3 sd_ref, 10 %) of the oracle's;
-  * every single run within 12 % of the oracle mean (a run that falls into a side minimum: the largest
-    deviation seen in the 32-seed studies is 8.3 %);
+  * every single run within max(12 %, 4 sd_ref) of the oracle mean (a run that falls into a side minimum: the
+    largest deviation seen in the 32-seed studies is 8.3 %; the sparse 3-D problem's own oracle spread is 9 %);
   * recovered distances: a run's distances among the first 48 points differ from the oracle's seed-mean
     by no more than 1.5 x the largest gap an oracle seed shows + 0.5 %.
 Measured means behind these tests: tests/study/gpu_contract_study.py, DESIGN.md section 2.
@@ -55,7 +55,7 @@ def check_runs(name, runs, mean_band=None, schedule=None):
     its = np.array([r.iterations for r in runs])
     band = contract_band(ref) if mean_band is None else mean_band
     assert abs(got.mean() - m) <= band, (name, schedule, got.mean(), m, band)
-    assert np.all(np.abs(got - m) <= 0.12 * m), (name, schedule, got.min(), got.max(), m)
+    assert np.all(np.abs(got - m) <= max(0.12 * m, 4.0 * ref["sd_final_mae"])), (name, schedule, got.min(), got.max(), m)
     assert abs(its.mean() - ref["mean_iterations"]) <= max(3.0 * ref["sd_iterations"],
                                                             ITER_BAND.get(name, 0.10) * ref["mean_iterations"])
     assert all(r.converged for r in runs) == all(x["converged"] for x in ref["runs"])
