@@ -190,6 +190,9 @@ def run_single(args):
                            "from the same start, bracketed by device synchronisations"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_refers_to": {"launch": "a one-stage launch (the whole matrix in one sweep)",
+                                           "algorithmic_bytes": bytes_iter,
+                                           "ratio": (traffic / bytes_iter) if traffic else None},
                      "kernel": "slab_stage_pipe_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
                      "launches": int(plain_launches), "fused_check_instance": fused,
                      "timing": "HIP events on the session stream around every stage launch, in a separate "
