@@ -109,3 +109,45 @@ def test_slab_fuzz_against_model(block):
         if np.abs(want2 - want).max() > 1e-10 * scale:
             continue
         assert np.abs(got - want).max() <= 1e-7 * scale, (n, dim, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_slab_one_shot_fuzz_properties(block, monkeypatch):
+    """The production entry on the slab path (random labels, edge-list-built block, fp32, checks fused into
+    one-stage sweeps) on random problems of ragged sizes, every instantiated coordinate count, thresholds,
+    duplicates, tiny and huge scales: (1) deterministic for a seed; (2) the reported MAE is the oracle's edge MAE of
+    the returned positions; (3) the controller fields are consistent; (4) fused and separate checks agree; (5)
+    keeping the caller's labels or relabelling changes nothing in kind (finite, same error class)."""
+    rng = np.random.default_rng(8100 + block)
+    for case in range(8):
+        n = int(rng.integers(2, 500))
+        dim = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 16]))
+        call = _fuzz_problem(rng, n, dim)
+        call = dataclasses.replace(call, n_iter=int(rng.integers(1, 120)), relative_epsilon=float(rng.choice([1e-2, 1e-3])))
+        seed = int(rng.integers(1, 2 ** 62))
+        outs = []
+        for fuse, keep in (("1", False), ("1", False), ("0", False), ("1", True)):
+            monkeypatch.setenv("TOPOLOW_FUSE_CHECKS", fuse)
+            try:
+                outs.append(_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="slab",
+                                                                 keep_labels=keep))
+            except _native.NativeError as e:
+                outs.append(e)
+        a, b, c, d = outs
+        if isinstance(a, Exception):
+            assert a.code == _native.ERR_NONFINITE and "Numerical instability at iteration" in str(a), (n, dim, a)
+            assert isinstance(b, Exception) and str(b) == str(a)
+            continue
+        assert not isinstance(b, Exception) and np.array_equal(a.positions, b.positions)
+        assert (a.converged, a.iterations, a.final_mae, a.final_k) == (b.converged, b.iterations, b.final_mae, b.final_k)
+        assert np.isfinite(a.positions).all() and a.positions.shape == (n, dim)
+        assert 0 <= a.iterations <= a.info["iterations_run"] <= call.n_iter
+        assert a.converged == (a.info["iterations_run"] < call.n_iter) or a.info["iterations_run"] == call.n_iter
+        sm, cnt = orc.edge_error(a.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        want = sm / cnt if cnt else 0.0
+        assert a.final_mae == pytest.approx(want, rel=5e-5, abs=1e-6 * max(1.0, float(np.abs(a.positions).max()))), (n, dim)
+        # separate error pass instead of the fused one: same trajectory, same verdicts
+        assert not isinstance(c, Exception), c
+        assert np.array_equal(a.positions, c.positions) and (a.converged, a.iterations) == (c.converged, c.iterations)
+        assert a.final_mae == pytest.approx(c.final_mae, rel=5e-6, abs=1e-12)
+        assert not isinstance(d, Exception) and np.isfinite(d.positions).all()

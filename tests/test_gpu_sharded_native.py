@@ -134,3 +134,34 @@ def test_config4_size_two_blocks_equal_one_block_and_host_overhead():
     assert r2.info["groups"] == 1
     assert r2.info["loop_seconds"] <= 1.10 * busy2, (r2.info, p2.info)
     assert r2.info["loop_seconds"] <= 1.35 * r1.info["loop_seconds"], (r1.info, r2.info)
+
+
+@pytest.mark.parametrize("thread_per_block", ["0", "1"])
+def test_sharded_fuzz_equals_single_session(thread_per_block, monkeypatch):
+    """Random problems (ragged sizes, 1..16 coordinates, thresholds, few or many iterations, every check cadence)
+    over 2..5 row blocks: the same trajectory and verdicts as the one-session run, bit for bit."""
+    from tests.test_gpu_fuzz import _fuzz_problem
+    import dataclasses
+    monkeypatch.setenv("TOPOLOW_SHARD_THREAD_PER_BLOCK", thread_per_block)
+    rng = np.random.default_rng(4200)
+    done = 0
+    for case in range(10):
+        n = int(rng.integers(9, 420))
+        dim = int(rng.choice([1, 2, 3, 5, 8, 10, 12]))
+        call = _fuzz_problem(rng, n, dim)
+        call = dataclasses.replace(call, n_iter=int(rng.integers(2, 90)), relative_epsilon=1e-3)
+        seed = int(rng.integers(1, 2 ** 62))
+        blocks = int(rng.integers(2, 6))
+        try:
+            one = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="slab")
+        except _native.NativeError as e:
+            with pytest.raises(_native.NativeError) as ei:
+                _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, devices=[0] * blocks)
+            assert str(ei.value) == str(e)
+            continue
+        got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, devices=[0] * blocks)
+        assert np.array_equal(got.positions, one.positions), (n, dim, blocks)
+        assert (got.converged, got.iterations, got.final_k) == (one.converged, one.iterations, one.final_k)
+        assert got.final_mae == pytest.approx(one.final_mae, rel=1e-5, abs=1e-12)
+        done += 1
+    assert done >= 6

@@ -121,25 +121,34 @@ inline void sharded_worker(ShardedRun& R, int r) {
   bool pend = false;
   int pend_iter1 = 0, pend_buf = 0;
   double pend_k = 0.0;
+  // Rank tables alternate between successive checks: with fused checks a block may already be pushing the NEXT
+  // check's (sum, count) -- it rides on the sweep that follows the barrier -- while another block's controller
+  // still reads this check's table behind the same barrier.  Two tables are enough: the push of check q + 2 is
+  // issued behind the barrier that follows controller(q) in every stream.  (With one table and one stream per
+  // block, controllers of different blocks saw different MAEs for the same check and stopped at different
+  // iterations: tests/test_gpu_sharded_native.py::test_sharded_fuzz_equals_single_session.)
+  long long n_check = 0;
   auto can_fuse = [&](const topolow_session* s) {
     return s->fuse_checks && s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && s->rows() % 2 == 0;
   };
   bool fusable = true;
   for (topolow_session* s : R.ss) fusable = fusable && can_fuse(s);
   auto separate_check = [&](int buf, int iter1, double k_after) -> bool {
+    const int tab = (int)(n_check & 1) * R.P;
+    ++n_check;
     for (int b : G.blocks) {
       topolow_session* s = R.ss[b];
       ProfScope prof(s, &s->prof_check);
       TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[buf].p, s->state.p);
       hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
-                         error_parts(s), s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, s->rank, s->state.p);
+                         error_parts(s), s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, tab + s->rank, s->state.p);
       HIP_TRY(hipGetLastError());
     }
     if (!exchange()) return false;
     for (int b : G.blocks) {
       topolow_session* s = R.ss[b];
       ProfScope prof(s, &s->prof_check);
-      launch_controller(s, s->pos[buf].p, iter1, k_after, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
+      launch_controller(s, s->pos[buf].p, iter1, k_after, s->rank_sum.p + tab, s->rank_cnt.p + tab, s->n_ranks);
     }
     return true;
   };
@@ -157,6 +166,8 @@ inline void sharded_worker(ShardedRun& R, int r) {
     const SlabGeom geo = slab_geom(lead->n, stages);
     const bool fuse_now = pend && geo.n_stages == 1;
     if (pend && !fuse_now) { if (!separate_check(pend_buf, pend_iter1, pend_k)) return; pend = false; }
+    const int tab = (int)(n_check & 1) * R.P;   // the table of the check this sweep carries, if any
+    if (fuse_now) ++n_check;
     for (int slot = 0; slot < geo.n_stages; ++slot) {
       const SlabRanges rg = slab_ranges(geo, lead->seed, iter, slot);
       for (int b : G.blocks) {
@@ -167,7 +178,7 @@ inline void sharded_worker(ShardedRun& R, int r) {
           const int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
           ProfScope prof(s, &s->prof_check);
           hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
-                             stage_blocks, s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, s->rank, s->state.p);
+                             stage_blocks, s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, tab + s->rank, s->state.p);
           HIP_TRY(hipGetLastError());
         }
       }
@@ -176,7 +187,7 @@ inline void sharded_worker(ShardedRun& R, int r) {
         for (int b : G.blocks) {
           topolow_session* s = R.ss[b];
           ProfScope prof(s, &s->prof_check);
-          launch_controller(s, s->pos[pend_buf].p, pend_iter1, pend_k, s->rank_sum.p, s->rank_cnt.p, s->n_ranks);
+          launch_controller(s, s->pos[pend_buf].p, pend_iter1, pend_k, s->rank_sum.p + tab, s->rank_cnt.p + tab, s->n_ranks);
         }
         pend = false;
       }
@@ -225,10 +236,10 @@ inline void sharded_wire(std::vector<topolow_session*>& ss) {
       if (!tab.empty())
         HIP_TRY(hipMemcpy(s->push_tab[b2].p, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
     }
-    s->rank_sum.alloc(P);
-    s->rank_cnt.alloc(P);
-    HIP_TRY(hipMemset(s->rank_sum.p, 0, sizeof(double) * P));
-    HIP_TRY(hipMemset(s->rank_cnt.p, 0, sizeof(unsigned long long) * P));
+    s->rank_sum.alloc(2 * P);   // two tables, alternating between successive checks (see sharded_worker)
+    s->rank_cnt.alloc(2 * P);
+    HIP_TRY(hipMemset(s->rank_sum.p, 0, sizeof(double) * 2 * P));
+    HIP_TRY(hipMemset(s->rank_cnt.p, 0, sizeof(unsigned long long) * 2 * P));
   }
   for (int a = 0; a < P; ++a) {
     topolow_session* s = ss[a];
