@@ -1,0 +1,153 @@
+// Probe of the symmetric sweep (topolow_amd/csrc/relax_symm.h) on synthetic data of config 3's shape:
+// checks one sweep + apply against a plain row-owner evaluation of the same update and times them.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I topolow_amd/csrc -I tools -o tools/symm_probe tools/symm_probe.hip
+// Run:   tools/symm_probe [n=10000] [workgroups per CU, 0 = occupancy] [reps=50]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "symm_sweep.h"
+
+using namespace topolow;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int DIM>
+__global__ void ref_kernel(const uint32_t* enc, int ld, const float* pos, const float* gplus, int n, double k, double c_rep,
+                           float* out, double* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double acc[DIM] = {};
+  double es = 0;
+  const float g = gplus[i];
+  const float ks = (float)(2.0 * k) / (4.0f * g + (float)k), cg = (float)(0.5 * c_rep) / g;
+  for (int c = 0; c < n; ++c) {
+    float dx[DIM], s = 0;
+    for (int d = 0; d < DIM; ++d) { dx[d] = pos[(size_t)c * DIM + d] - pos[(size_t)i * DIM + d]; s = fmaf(dx[d], dx[d], s); }
+    const float r = sqrtf(s), inv = 1.0f / (r + 0.01f);
+    const uint32_t w = enc[(size_t)i * ld + c];
+    const bool sp = (w & 0x7f800000u) != 0x7f800000u;
+    const float t = bits_f32(w);
+    const float coef = sp ? (t - r) * inv * ks : inv * inv * inv * cg;
+    for (int d = 0; d < DIM; ++d) acc[d] += (double)dx[d] * coef;
+    if (sp && c > i) es += fabs((double)t - r);
+  }
+  for (int d = 0; d < DIM; ++d) out[(size_t)i * DIM + d] = (float)((double)pos[(size_t)i * DIM + d] - acc[d]);
+  err[i] = es;
+}
+
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  constexpr int DIM = 5;
+  constexpr int W = SymRec<DIM>::W;
+  const int n = argc > 1 ? atoi(argv[1]) : 10000;
+  const int KT = argc > 2 ? atoi(argv[2]) : 0;
+  const int reps = argc > 3 ? atoi(argv[3]) : 50;
+  const int n32 = (n + 31) & ~31, ld = (n + 63) & ~63, T = n32 / 32;
+  const double k = 2.3, c_rep = 0.01;
+  std::mt19937_64 rng(1);
+  std::normal_distribution<float> nd(0.f, 3.f);
+  std::uniform_real_distribution<float> ud(0.f, 1.f);
+  std::vector<float> pos((size_t)n * DIM), g(n);
+  for (auto& v : pos) v = nd(rng);
+  std::vector<uint32_t> enc((size_t)n32 * ld, kInfWord);
+  std::vector<int> deg(n, 0);
+  for (int i = 0; i < n; ++i)
+    for (int c = i + 1; c < n; ++c)
+      if (ud(rng) < 0.3f) {
+        float s = 0;
+        for (int d = 0; d < DIM; ++d) { const float q = pos[(size_t)i * DIM + d] - pos[(size_t)c * DIM + d]; s += q * q; }
+        const uint32_t w = encode_target(std::sqrt(s) * (1.0 + 0.05 * nd(rng) / 3.0), 0);
+        enc[(size_t)i * ld + c] = w;
+        enc[(size_t)c * ld + i] = w;
+        ++deg[i]; ++deg[c];
+      }
+  for (int i = 0; i < n; ++i) g[i] = (float)(deg[i] + 2);
+  for (auto& v : pos) v += 0.3f * nd(rng) / 3.0f;   // perturb so that the springs are loaded
+
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, symm_sweep_kernel<DIM, false, false>, 64 * kSymWaves, 0));
+  const int grid = (KT > 0 ? KT : occ) * cus;
+  const SymPlan plan = relax_symm_plan(n32, grid * kSymWaves);
+  const std::vector<SymUnit>& units = plan.units;
+  const std::vector<int2>& row_units = plan.row_units;
+  const int n_units = (int)units.size();
+  printf("n %d  tiles/row %d  occupancy %d WG/CU  grid %d  units %d  colpart %.1f MB rowpart %.1f MB\n", n, T, occ, grid, n_units,
+         (double)T * n32 * DIM * 4 / 1e6, (double)n_units * 32 * DIM * 4 / 1e6);
+
+  // tile-major copy of the upper triangle
+  std::vector<uint32_t> tenc((size_t)sym_tile_index(T - 1, T - 1, T) * 1024 + 1024, kInfWord);
+  for (int I = 0; I < T; ++I)
+    for (int J = I; J < T; ++J) {
+      uint32_t* t = tenc.data() + (size_t)sym_tile_index(I, J, T) * 1024;
+      for (int r = 0; r < 32; ++r)
+        for (int c = 0; c < 32; ++c) t[sym_word_in_tile(r, c)] = enc[(size_t)(I * 32 + r) * ld + J * 32 + c];
+    }
+  uint32_t* d_tenc;
+  CK(hipMalloc(&d_tenc, tenc.size() * 4)); CK(hipMemcpy(d_tenc, tenc.data(), tenc.size() * 4, hipMemcpyHostToDevice));
+  uint32_t* d_enc; float *d_pos, *d_g, *d_rec, *d_rec2, *d_out, *d_ref, *d_rowp, *d_colp; double *d_err, *d_psum; unsigned long long* d_pcnt;
+  SymUnit* d_units; int2* d_ru; int* d_wf;
+  CK(hipMalloc(&d_enc, enc.size() * 4)); CK(hipMemcpy(d_enc, enc.data(), enc.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_pos, pos.size() * 4)); CK(hipMemcpy(d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_g, n * 4)); CK(hipMemcpy(d_g, g.data(), n * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_rec, (size_t)n32 * W * 4)); CK(hipMalloc(&d_rec2, (size_t)n32 * W * 4));
+  CK(hipMalloc(&d_out, pos.size() * 4)); CK(hipMalloc(&d_ref, pos.size() * 4));
+  CK(hipMalloc(&d_rowp, (size_t)n_units * 32 * DIM * 4)); CK(hipMalloc(&d_colp, (size_t)T * n32 * DIM * 4));
+  CK(hipMalloc(&d_err, n * 8)); CK(hipMalloc(&d_psum, n_units * 8)); CK(hipMalloc(&d_pcnt, n_units * 8));
+  CK(hipMalloc(&d_units, n_units * sizeof(SymUnit))); CK(hipMemcpy(d_units, units.data(), n_units * sizeof(SymUnit), hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_ru, T * sizeof(int2))); CK(hipMemcpy(d_ru, row_units.data(), T * sizeof(int2), hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_wf, plan.wave_first.size() * 4)); CK(hipMemcpy(d_wf, plan.wave_first.data(), plan.wave_first.size() * 4, hipMemcpyHostToDevice));
+
+  hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((n32 + 255) / 256), dim3(256), 0, 0, d_pos, d_g, d_rec, n, n32, k, c_rep);
+  hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((n32 + 255) / 256), dim3(256), 0, 0, d_pos, d_g, d_rec2, n, n32, k, c_rep);
+  CK(hipDeviceSynchronize()); printf("records done\n");
+  hipLaunchKernelGGL(ref_kernel<DIM>, dim3((n + 63) / 64), dim3(64), 0, 0, d_enc, ld, d_pos, d_g, n, k, c_rep, d_ref, d_err);
+  CK(hipDeviceSynchronize()); printf("ref done\n");
+  hipLaunchKernelGGL((symm_sweep_kernel<DIM, false, true>), dim3(grid), dim3(64 * kSymWaves), 0, 0, d_tenc, d_rec, d_units,
+                     d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt);
+  CK(hipDeviceSynchronize()); printf("sweep done\n");
+  hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(256), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,
+                     k * 0.99, c_rep, 1, (RunState*)nullptr);
+  CK(hipDeviceSynchronize()); printf("apply done\n");
+  std::vector<float> out(pos.size()), ref(pos.size());
+  std::vector<double> err(n), psum(n_units);
+  CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(ref.data(), d_ref, ref.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(err.data(), d_err, n * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(psum.data(), d_psum, n_units * 8, hipMemcpyDeviceToHost));
+  double maxd = 0, move = 0, e_ref = 0, e_sym = 0;
+  for (size_t q = 0; q < out.size(); ++q) {
+    maxd = std::max(maxd, (double)std::fabs(out[q] - ref[q]));
+    move = std::max(move, (double)std::fabs(ref[q] - pos[q]));
+  }
+  for (double v : err) e_ref += v;
+  for (double v : psum) e_sym += v;
+  printf("max |sym - ref| %.3g (largest move %.3g)   err sum ref %.9g sym %.9g\n", maxd, move, e_ref, e_sym);
+
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto time = [&](auto&& fn, const char* what) {
+    for (int q = 0; q < 5; ++q) fn();
+    CK(hipEventRecord(e0));
+    for (int q = 0; q < reps; ++q) fn();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-34s %8.2f us\n", what, 1e3 * ms / reps);
+  };
+  auto sweep = [&](auto err_tag) {
+    hipLaunchKernelGGL((symm_sweep_kernel<DIM, false, decltype(err_tag)::value>), dim3(grid), dim3(64 * kSymWaves), 0, 0, d_tenc, d_rec,
+                       d_units, d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt);
+  };
+  auto apply = [&]() {
+    hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(256), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,
+                       k * 0.99, c_rep, 1, (RunState*)nullptr);
+  };
+  time([&]() { sweep(std::false_type{}); }, "sweep");
+  time([&]() { apply(); }, "apply");
+  time([&]() { sweep(std::false_type{}); apply(); }, "sweep + apply");
+  time([&]() { sweep(std::true_type{}); apply(); }, "sweep<ERR> + apply");
+  return 0;
+}
