@@ -443,50 +443,63 @@ def _bench_replicas(args, rank, world, local, coll):
     s.load_coo(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.degrees)
     s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
 
-    def fresh():
+    def fresh(total):
         s.set_positions(call.initial_positions)
-        s.begin(W + K, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 2024 + rank, args.stages)
+        s.begin(total, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 2024 + rank, args.stages)
 
-    def timed_pass():
-        """W untimed iterations, then EXACTLY K timed ones bracketed by barrier + device synchronisation; the
-        pass's time is the MAX over the ranks."""
-        fresh()
-        done = 0
-        while done < W:
-            done += s.enqueue(W - done)
-        s.sync()
-        torch.cuda.synchronize()
-        coll.barrier()
-        t0 = time.perf_counter()
-        done = 0
-        while done < K:
-            done += s.enqueue(K - done)
-        s.sync()
-        torch.cuda.synchronize()
-        coll.barrier()
-        return coll.max_float(time.perf_counter() - t0)
+    # the job: this rank's embedding relaxed to the controller's own stop; its length (max over ranks) sets how
+    # many K-iteration slices a rotation has (bench.py: run_single has the reasoning)
+    s.set_positions(call.initial_positions)
+    s.begin(1000, k0, cool, c_rep, 1e-4, 5, 3, 2024 + rank, args.stages)
+    s.run()
+    iters_run, _st, _m = s.sync()
+    s.finish()
+    n_job = int(coll.max_float(float(iters_run)))
+    P = max(1, -(-n_job // K))
 
-    passes = []
-    while (sum(passes) < args.min_timed or len(passes) < 3) and len(passes) < 200:   # identical on every rank
-        passes.append(timed_pass())
-    elapsed = float(np.median(passes))
+    def rotation():
+        """W untimed iterations of a throw-away run, then the job from its start in P slices of EXACTLY K
+        iterations, every slice bracketed by barrier + device synchronisation; a slice's time is the MAX over the
+        ranks."""
+        if W > 0:
+            fresh(W)
+            done = 0
+            while done < W:
+                done += s.enqueue(W - done)
+            s.sync()
+        fresh(P * K)
+        slices = []
+        for _p in range(P):
+            torch.cuda.synchronize()
+            coll.barrier()
+            t0 = time.perf_counter()
+            done = 0
+            while done < K:
+                done += s.enqueue(K - done)
+            s.sync()
+            torch.cuda.synchronize()
+            coll.barrier()
+            slices.append(coll.max_float(time.perf_counter() - t0))
+        return slices
+
+    rotations = []
+    while (sum(map(sum, rotations)) < args.min_timed or len(rotations) < 3) and len(rotations) < 100:   # same on every rank
+        rotations.append(rotation())
+    rates = [world * K / float(np.mean(r)) for r in rotations]
+    elapsed = world * K / float(np.median(rates))
     res = s.finish()
-    # roofline of the dominant kernel on this rank (profiled pass; rank 0 reports)
-    fresh()
-    done = 0
-    while done < W:
-        done += s.enqueue(W - done)
-    s.sync()
+    # roofline of the dominant kernel on this rank (profiled pass over the same iterations; rank 0 reports)
+    fresh(P * K)
     s.set_profiling(True)
     done = 0
-    while done < K:
-        done += s.enqueue(K - done)
+    while done < P * K:
+        done += s.enqueue(P * K - done)
     fused_ms, fused_launches = s.profile_fused()
     stage_ms, launches, check_ms, checks = s.profile()
     s.set_profiling(False)
     bytes_iter = s.bytes_per_iteration
-    per_launch = bytes_iter / (launches / K)
     plain = max(launches - fused_launches, 1)
+    per_launch = bytes_iter * (P * K - fused_launches) / plain     # fused launches are whole-matrix sweeps
     avg_s = (stage_ms - fused_ms) * 1e-3 / plain
     achieved = per_launch / avg_s / 1e9
     s.close()
@@ -498,12 +511,14 @@ def _bench_replicas(args, rank, world, local, coll):
         "config": {"workload": f"config 3 replicated: {world} independent embeddings (one per GPU), each "
                                f"synthetic N={n}, 70% missing, ndim=5, k0=5, cooling=0.01, c_repulsion=0.01",
                    "n_points": n, "ndim": ndim, "schedule": "slab", "parallelism": f"replicas x{world}",
-                   "stages_per_iteration": launches / K},
-        "timing": {"passes": len(passes), "timed_seconds": float(sum(passes)),
-                   "iterations_per_s": {"min": world * K / max(passes), "median": world * K / elapsed,
-                                        "max": world * K / min(passes)},
-                   "note": "value = world * K / median pass; a pass = W untimed + exactly K timed iterations per rank "
-                           "between barriers and device synchronisations, its time the MAX over ranks"},
+                   "stages_per_iteration": launches / (P * K)},
+        "timing": {"job_iterations": n_job, "slices_per_rotation": P, "rotations": len(rotations),
+                   "timed_seconds": float(sum(map(sum, rotations))),
+                   "iterations_per_s": {"min": min(rates), "median": float(np.median(rates)), "max": max(rates)},
+                   "note": "every rank's job (its embedding to the controller's own stop) is timed in slices of exactly "
+                           "K iterations between barriers and device synchronisations, a slice's time the MAX over "
+                           "ranks, after W untimed iterations of a throw-away run; value = world * K / mean slice, "
+                           "median over rotations"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": None, "kernel": "slab_stage_pipe_kernel<5,float>",
                      "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per_launch,
