@@ -1,0 +1,42 @@
+"""bench.py's contract on a small instance of its workload (run with -m gpu): one JSON line with the fields the
+driver reads, `value` = the job's average rate whatever --steps / --warmup are."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--points", "2048", "--no-cpu-baseline",
+                        "--min-timed", "0.05", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_and_job_average():
+    a = run_bench("--steps", "20", "--warmup", "5")
+    b = run_bench("--steps", "150", "--warmup", "0")
+    for d, k, w in ((a, 20, 5), (b, 150, 0)):
+        assert d["metric"].startswith("relaxation iterations/sec") and d["unit"] == "iterations/s"
+        assert d["n_gpus"] == 1 and d["steps"] == k and d["warmup"] == w and d["higher_is_better"] is True
+        assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+        assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
+        t = d["timing"]
+        assert t["slices_per_rotation"] == -(-t["job_iterations"] // k) and t["rotations"] >= 3
+        assert len(t["iterations_per_s_by_slice"]) == t["slices_per_rotation"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["launches"] > 0
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+        w_run = d["whole_run"]
+        assert w_run["converged"] and w_run["iterations_run"] == t["job_iterations"]
+    # the same job: the two slicings agree with each other and with the job timed in one piece
+    assert a["timing"]["job_iterations"] == b["timing"]["job_iterations"]
+    assert abs(a["value"] / b["value"] - 1.0) < 0.15, (a["value"], b["value"])
+    assert abs(a["value"] / a["whole_run"]["iterations_per_s"] - 1.0) < 0.25
