@@ -179,3 +179,28 @@ def test_fold_builder_equals_the_dense_preparation(source):
     assert np.array_equal(s2.edge_dist, s3.edge_dist) and np.array_equal(s2.degrees, s3.degrees)
     assert s2.order is None and np.array_equal(d2.edge_i, s2.edge_i) and np.array_equal(d2.degrees, s2.degrees)
     assert np.array_equal(d2.initial_positions, s2.initial_positions)
+
+
+def test_folds_built_side_by_side_equal_the_sequential_loop():
+    """cv.build_fold_calls(parallel=True) -- one sequential pass over the random stream, the list work on a thread
+    pool -- hands over exactly the calls, holdouts and stream position of the fold-by-fold loop."""
+    m = _coded_random(60, 11, True)
+    builder = cv.FoldBuilder(m)
+    rng0 = np.random.default_rng(17)
+    sets = [dict(N=int(rng0.integers(2, 7)), k0=float(rng0.uniform(0.5, 10)), cooling_rate=0.02, c_repulsion=0.01)
+            for _ in range(9)]
+    sets[3]["k0"] = -1.0                                   # a set the parameter checks reject: NA rows, no draws
+    ra, rb = np.random.default_rng(5), np.random.default_rng(5)
+    seq = cv.build_fold_calls(m, builder, sets, 4, ra, 60, 1e-4, False, parallel=False)
+    par = cv.build_fold_calls(m, cv.FoldBuilder(m), sets, 4, rb, 60, 1e-4, False, parallel=True)
+    assert ra.uniform() == rb.uniform()
+    assert seq[1] == par[1] and len(seq[0]) == len(par[0]) == 36
+    for a, b, ha, hb in zip(seq[0], par[0], seq[3], par[3]):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        for f in ("initial_positions", "degrees", "edge_i", "edge_j", "edge_dist", "edge_thresh"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert a.names == b.names and (a.k0, a.cooling_rate, a.n_iter) == (b.k0, b.cooling_rate, b.n_iter)
+        assert all(np.array_equal(x, y) for x, y in zip(ha, hb))
+    assert sum(c is None for c in seq[0]) == 4

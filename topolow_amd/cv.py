@@ -9,7 +9,9 @@ set becomes one workgroup of a single `topolow_optimize_layout_exact_batch` laun
 from __future__ import annotations
 
 import math
+import os
 import warnings
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -168,15 +170,31 @@ class FoldBuilder:
         (column-major) cell indices `picks` and their mirrors.  The list work runs in the library's
         host code (`topolow_cv_fold`, topolow_amd/csrc/relax_fold.h); `fold_numpy` is the same thing
         in NumPy and the two are tested to agree to the last bit."""
-        n = self.n
+        return self.fold_from_draw(picks, ndim, mapping_max_iter, k0, cooling_rate, c_repulsion, relative_epsilon,
+                                   convergence_counter, convergence_check_freq, preserve_order, rng=rng)
+
+    def cells(self):
         if self._cells is None:
-            self._cells = _native.CellList(n, self.rows, self.cols, self.vals, self.codes, self.pos_of)
+            self._cells = _native.CellList(self.n, self.rows, self.cols, self.vals, self.codes, self.pos_of)
+        return self._cells
+
+    def fold_from_draw(self, picks: np.ndarray, ndim: int, mapping_max_iter, k0, cooling_rate, c_repulsion,
+                       relative_epsilon, convergence_counter, convergence_check_freq, preserve_order, rng=None,
+                       unit_draw=None):
+        """`fold` with the start positions' random numbers either drawn here (rng) or handed in (unit_draw: the
+        (ndim, n - 1) array rng.random would have returned at this point of the stream -- uniform(0, 2a) is
+        2a * random(), bit for bit), so that many folds can be built side by side after one sequential pass
+        over the random stream (likelihood_sweep)."""
+        n = self.n
         order, degrees, ei, ej, ed, et, hi, hj, ht, vmax = _native.cv_fold(
-            self._cells, picks, preserve_order, self.m.names is not None)
+            self.cells(), picks, preserve_order, self.m.names is not None)
         if ei.shape[0] == 0:
             raise ValueError("No valid off-diagonal measurements found in dissimilarity matrix")
         init_step = vmax / n
-        steps = rng.uniform(0.0, 2.0 * init_step, size=(int(ndim), n - 1)).T
+        if unit_draw is None:
+            steps = rng.uniform(0.0, 2.0 * init_step, size=(int(ndim), n - 1)).T
+        else:
+            steps = (0.0 + (2.0 * init_step - 0.0) * unit_draw).T      # Generator.uniform's own arithmetic
         init = np.vstack([np.zeros((1, int(ndim))), np.cumsum(steps, axis=0)])
         names = self.m.names
         if names is not None and order is not None:
@@ -242,6 +260,69 @@ class FoldBuilder:
         return call, hold
 
 
+def _fold_workers() -> int:
+    """Threads that build folds side by side: the cores this process may use, at most 16."""
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def build_fold_calls(m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order,
+                     parallel: bool):
+    """All folds of all parameter sets: (calls, owners, masked inputs, holdouts).  One sequential pass over the
+    random stream (fold picks, then each fold's start-position draws, in the order the reference's loop consumes
+    them); parallel = True: the list work of the folds (topolow_cv_fold, which releases the interpreter lock) then
+    runs on a thread pool.  A fold that fails draws nothing in the sequential order, so a failure inside the pool
+    makes the caller redo the pass with parallel = False from the same stream state (likelihood_sweep)."""
+    tiny = core.CodedMatrix(np.array([[0.0, 1.0], [1.0, 0.0]]), np.zeros((2, 2), dtype=np.int32))
+    calls, owners, inputs, holds, jobs = [], [], [], [], []
+    n_pts = m.values.shape[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s_idx, ps in enumerate(param_sets):
+            fold_sets = builder.folds(folds, rng) if builder is not None else make_folds(m.values, folds, rng)
+            set_ok = True
+            if builder is not None:
+                try:    # the parameter checks of R/core.R:202-264, once per set instead of once per fold
+                    core._validate(tiny, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"],
+                                   ps["c_repulsion"], relative_epsilon, 5, 3, None)
+                except ValueError:
+                    set_ok = False
+            for h in fold_sets:
+                masked, hold, call = None, None, None
+                try:
+                    if builder is None:
+                        masked = m.masked(h % n_pts, h // n_pts)
+                        call = core.prepare_layout_call(masked, int(ps["N"]), mapping_max_iter, ps["k0"],
+                                                        ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
+                                                        5, None, False, 3, preserve_order, rng)
+                    elif set_ok and parallel:
+                        jobs.append((len(calls), h, ps, rng.random((int(ps["N"]), n_pts - 1))))
+                    elif set_ok:
+                        call, hold = builder.fold(h, int(ps["N"]), mapping_max_iter, ps["k0"],
+                                                  ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
+                                                  5, 3, preserve_order, rng)
+                except ValueError:
+                    call = None  # the reference's tryCatch turns a failed fold into an NA row
+                calls.append(call)
+                owners.append(s_idx)
+                inputs.append(masked)
+                holds.append(hold)
+        if jobs:
+            builder.cells()
+
+            def one(job):
+                q, h, ps, u = job
+                return q, builder.fold_from_draw(h, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"],
+                                                 ps["c_repulsion"], relative_epsilon, 5, 3, preserve_order,
+                                                 unit_draw=u)
+            with ThreadPoolExecutor(max_workers=_fold_workers()) as pool:
+                for q, (call, hold) in pool.map(one, jobs):
+                    calls[q], holds[q] = call, hold
+    return calls, owners, inputs, holds
+
+
 def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]], mapping_max_iter: int,
                      relative_epsilon: float, folds: int = 20, preserve_order: bool = False,
                      rng: Optional[np.random.Generator] = None, precision: str = "f64",
@@ -262,46 +343,19 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     if path not in ("sparse", "dense"):
         raise ValueError("path must be 'sparse' or 'dense'")
     builder = FoldBuilder(m) if path == "sparse" else None
-    calls, owners, inputs, holds = [], [], [], []
-    tiny = core.CodedMatrix(np.array([[0.0, 1.0], [1.0, 0.0]]), np.zeros((2, 2), dtype=np.int32))
     if builder is not None:      # the matrix half of R/core.R:202-264 once; per set only the parameters
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             core._validate(m, 2, 1, 1.0, 0.5, 1.0, 1.0, 1, 1, None)
-    for s_idx, ps in enumerate(param_sets):
-        fold_sets = builder.folds(folds, rng) if builder is not None else make_folds(m.values, folds, rng)
-        n_pts = m.values.shape[0]
-        set_ok = True
-        if builder is not None:
-            try:    # the parameter checks of R/core.R:202-264, once per set instead of once per fold
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    core._validate(tiny, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"],
-                                   ps["c_repulsion"], relative_epsilon, 5, 3, None)
-            except ValueError:
-                set_ok = False
-        for h in fold_sets:
-            masked, hold = None, None
-            try:
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    if builder is None:
-                        masked = m.masked(h % n_pts, h // n_pts)
-                        call = core.prepare_layout_call(masked, int(ps["N"]), mapping_max_iter, ps["k0"],
-                                                        ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
-                                                        5, None, False, 3, preserve_order, rng)
-                    elif set_ok:
-                        call, hold = builder.fold(h, int(ps["N"]), mapping_max_iter, ps["k0"],
-                                                  ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
-                                                  5, 3, preserve_order, rng)
-                    else:
-                        call = None
-            except ValueError:
-                call = None  # the reference's tryCatch turns a failed fold into an NA row
-            calls.append(call)
-            owners.append(s_idx)
-            inputs.append(masked)
-            holds.append(hold)
+    state0 = rng.bit_generator.state
+    try:
+        calls, owners, inputs, holds = build_fold_calls(
+            m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order,
+            parallel=builder is not None and len(param_sets) * folds >= 16)
+    except Exception:
+        rng.bit_generator.state = state0
+        calls, owners, inputs, holds = build_fold_calls(
+            m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order, parallel=False)
     live = [q for q, c in enumerate(calls) if c is not None]
     seeds = [int(rng.integers(0, 2 ** 63 - 1)) for _ in live]
     results, secs = ([], 0.0)
