@@ -38,5 +38,7 @@ def test_bench_line_and_job_average():
         assert w_run["converged"] and w_run["iterations_run"] == t["job_iterations"]
     # the same job: the two slicings agree with each other and with the job timed in one piece
     assert a["timing"]["job_iterations"] == b["timing"]["job_iterations"]
-    assert abs(a["value"] / b["value"] - 1.0) < 0.15, (a["value"], b["value"])
-    assert abs(a["value"] / a["whole_run"]["iterations_per_s"] - 1.0) < 0.25
+    # (at this size an iteration is ~15 us, so the two synchronisations around a 20-iteration slice weigh 10-20 %; at
+    # config 3's size the same comparison is within 2 %: DESIGN.md section 6)
+    assert abs(a["value"] / b["value"] - 1.0) < 0.35, (a["value"], b["value"])
+    assert abs(a["value"] / a["whole_run"]["iterations_per_s"] - 1.0) < 0.35
