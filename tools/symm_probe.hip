@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL((symm_sweep_kernel<DIM, false, true>), dim3(grid), dim3(64 * kSymWaves), 0, 0, d_tenc, d_rec, d_units,
                      d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt);
   CK(hipDeviceSynchronize()); printf("sweep done\n");
-  hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(256), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,
+  hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(32 * kSymApplyParts), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,
                      k * 0.99, c_rep, 1, (RunState*)nullptr);
   CK(hipDeviceSynchronize()); printf("apply done\n");
   std::vector<float> out(pos.size()), ref(pos.size());
@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
                        d_units, d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt);
   };
   auto apply = [&]() {
-    hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(256), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,
+    hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(32 * kSymApplyParts), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,
                        k * 0.99, c_rep, 1, (RunState*)nullptr);
   };
   time([&]() { sweep(std::false_type{}); }, "sweep");

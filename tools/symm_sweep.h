@@ -373,28 +373,30 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
 // column sum is sum (p_i - p_c)... with dx = p_c' - p_i' taken row-side, hence the sign).
 // Writes the positions (row-major n4 x DIM, as every other kernel reads them) and the records of the NEXT
 // iteration (k_next).
+constexpr int kSymApplyParts = 32;   // threads of the apply kernel: 32 parts x 32 points (a tile-row)
 template <int DIM>
-__global__ __launch_bounds__(256) void symm_apply_kernel(
+__global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
     const float* __restrict__ rec, float* __restrict__ rec_next, float* __restrict__ pos_out, const float* __restrict__ gplus,
     const float* __restrict__ rowpart, const float* __restrict__ colpart, const int2* __restrict__ row_units, int n,
     int n32, double k_next, double c_rep, int iter1, RunState* st) {
   if (st != nullptr && st->stopped) return;
   constexpr int W = SymRec<DIM>::W;
-  __shared__ float red[8][kSymTile][DIM];
+  __shared__ float red[kSymApplyParts][kSymTile][DIM];
   const int I = blockIdx.x;
   const int part = threadIdx.x >> 5, pt = threadIdx.x & 31;
   const int i = I * kSymTile + pt;
   float acc[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc[d] = 0.0f;
-  // column sums of the tile-rows above (added), this thread's share: I' = part, part + 8, ...
-  for (int Ip = part; Ip < I; Ip += 8) {
+  // column sums of the tile-rows above (added), this thread's share: I' = part, part + 32, ... (the last tile-rows
+  // sum ~n/32 strips each: with 8 parts their serial chains of loads set the kernel's time, 15 us at n = 10 000)
+  for (int Ip = part; Ip < I; Ip += kSymApplyParts) {
     const float* src = colpart + ((size_t)Ip * n32 + i) * DIM;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) acc[d] += src[d];
   }
   const int2 ru = row_units[I];
-  for (int q = part; q < ru.y; q += 8) {
+  for (int q = part; q < ru.y; q += kSymApplyParts) {
     const float* src = rowpart + ((size_t)(ru.x + q) * kSymTile + pt) * DIM;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) acc[d] -= src[d];
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void symm_apply_kernel(
     for (int d = 0; d < DIM; ++d) {
       float t = red[0][pt][d];
 #pragma unroll
-      for (int p = 1; p < 8; ++p) t += red[p][pt][d];
+      for (int p = 1; p < kSymApplyParts; ++p) t += red[p][pt][d];
       out[d] = rec[(size_t)i * W + d] + t;
       finite = finite && isfinite(out[d]);
       pos_out[(size_t)i * DIM + d] = out[d];
