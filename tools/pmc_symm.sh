@@ -5,7 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -I topolow_amd/csrc -I tools -o /tmp/symm_probe tools/symm_probe.hip
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -I topolow_amd/csrc -o /tmp/symm_probe tools/symm_probe.hip
 timeout -k 5 120 /tmp/symm_probe 10000 0 50 > gpurun_out/symm_probe.log 2>&1
 run() { timeout -k 5 120 rocprofv3 --pmc $2 --output-format csv -d gpurun_out/symm_pmc_$1 -- /tmp/symm_probe 10000 0 3 > gpurun_out/symm_pmc_$1.log 2>&1; }
 run a "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY"

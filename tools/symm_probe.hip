@@ -1,6 +1,6 @@
 // Probe of the symmetric sweep (topolow_amd/csrc/relax_symm.h) on synthetic data of config 3's shape:
 // checks one sweep + apply against a plain row-owner evaluation of the same update and times them.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I topolow_amd/csrc -I tools -o tools/symm_probe tools/symm_probe.hip
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I topolow_amd/csrc -o tools/symm_probe tools/symm_probe.hip
 // Run:   tools/symm_probe [n=10000] [workgroups per CU, 0 = occupancy] [reps=50]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -9,7 +9,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
-#include "symm_sweep.h"
+#include "relax_symm.h"
 
 using namespace topolow;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -108,7 +108,7 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(ref_kernel<DIM>, dim3((n + 63) / 64), dim3(64), 0, 0, d_enc, ld, d_pos, d_g, n, k, c_rep, d_ref, d_err);
   CK(hipDeviceSynchronize()); printf("ref done\n");
   hipLaunchKernelGGL((symm_sweep_kernel<DIM, false, true>), dim3(grid), dim3(64 * kSymWaves), 0, 0, d_tenc, d_rec, d_units,
-                     d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt);
+                     d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt, 0ull);
   CK(hipDeviceSynchronize()); printf("sweep done\n");
   hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(32 * kSymApplyParts), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,
                      k * 0.99, c_rep, 1, (RunState*)nullptr);
@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
   };
   auto sweep = [&](auto err_tag) {
     hipLaunchKernelGGL((symm_sweep_kernel<DIM, false, decltype(err_tag)::value>), dim3(grid), dim3(64 * kSymWaves), 0, 0, d_tenc, d_rec,
-                       d_units, d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt);
+                       d_units, d_wf, d_rowp, d_colp, n32, (const RunState*)nullptr, d_psum, d_pcnt, 0ull);
   };
   auto apply = [&]() {
     hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(32 * kSymApplyParts), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, n32,

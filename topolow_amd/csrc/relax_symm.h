@@ -1,4 +1,4 @@
-// tools/symm_sweep.h -- EXPERIMENT, not part of libtopolow_relax.so: the symmetric sweep for one-stage iterations
+// topolow_amd/csrc/relax_symm.h -- the symmetric sweep: ONE-stage iterations of the slab path on one GPU (fp32)
 //
 // With one stage per iteration every point moves by the sum of its own halves of all its pairs, all taken from
 // the positions the previous iteration left (relax_kernels.h, slab_stage_pipe_kernel with S' = 1).  The row-owner
@@ -28,7 +28,7 @@
 namespace topolow {
 
 #ifndef TOPOLOW_SYM_MINW
-#define TOPOLOW_SYM_MINW 3
+#define TOPOLOW_SYM_MINW 2
 #endif
 constexpr int kSymTile = 32;
 constexpr int kSymWaves = 4;   // waves per workgroup (independent of one another)
@@ -163,12 +163,14 @@ __device__ __forceinline__ void sym_pair(const float (&pc)[DIM], float ksc, floa
 // colpart: [n_tile_rows][n32][DIM]  column sums of a tile-row (sum of dx * coef_c over the tile-row's 32 rows),
 //          written for columns right of the tile-row's diagonal tile only
 // part_sum / part_cnt: [n_units]  ERR launches: sum |t - r| and count over the unit's contributing pairs (each
-//          unordered pair once; the diagonal tile meets its pairs twice and is weighted 1/2)
+//          unordered pair once; the diagonal tile meets its pairs twice and is weighted 1/2); fixed_cnt: the count of
+//          a threshold-free block (every measured pair contributes whatever the positions are), stored in slot 0
 template <int DIM, bool ANYTHR, bool ERR>
 __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_kernel(
     const uint32_t* __restrict__ enc, const float* __restrict__ rec, const SymUnit* __restrict__ units,
     const int* __restrict__ wave_first, float* __restrict__ rowpart, float* __restrict__ colpart, int n32,
-    const RunState* st, double* __restrict__ part_sum, unsigned long long* __restrict__ part_cnt) {
+    const RunState* st, double* __restrict__ part_sum, unsigned long long* __restrict__ part_cnt,
+    unsigned long long fixed_cnt) {
   if (st != nullptr && st->stopped) return;
   constexpr int W = SymRec<DIM>::W;
   constexpr int kRecVec = W / 4;                   // 16-byte pieces per record
@@ -361,7 +363,9 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
       for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
       if (lane == 0) {
         part_sum[slot] = s;
-        part_cnt[slot] = (unsigned long long)cnt_unit2;   // wave-uniform (ballots); halved by the caller's count rule
+        // threshold-free block: the number of contributing pairs is the host's; otherwise the wave's ballots
+        // (cnt_unit2 counted every pair twice, the diagonal tile's two visits once each: always even)
+        part_cnt[slot] = ANYTHR ? (unsigned long long)(cnt_unit2 >> 1) : (slot == 0 ? fixed_cnt : 0ull);
       }
     }
   }
@@ -447,6 +451,32 @@ __global__ __launch_bounds__(256) void symm_records_kernel(const float* __restri
   }
 #pragma unroll
   for (int d = DIM + 2; d < W; ++d) r[d] = 0.0f;
+}
+
+// The tile-major copy of the upper triangle from the row-major encoded block (rows x ld words, rows >= n): one
+// workgroup per tile, 4 words per thread; rows past the block's end read as unmeasured.
+__global__ __launch_bounds__(256) void symm_tiles_kernel(const uint32_t* __restrict__ enc, int rows, int ld,
+                                                        uint32_t* __restrict__ tenc, int T) {
+  // tile index -> (I, J): tile-rows are T, T - 1, ... tiles long
+  long long t = blockIdx.x;
+  int I = 0;
+  {
+    // largest I with I T - I (I - 1) / 2 <= t  (closed form, then corrected for rounding)
+    const double b = 2.0 * T + 1.0;
+    I = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    while (I > 0 && (long long)I * T - (long long)I * (I - 1) / 2 > t) --I;
+    while ((long long)(I + 1) * T - (long long)(I + 1) * I / 2 <= t) ++I;
+  }
+  const int J = I + (int)(t - ((long long)I * T - (long long)I * (I - 1) / 2));
+  uint32_t* dst = tenc + (size_t)t * (kSymTile * kSymTile);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cell = threadIdx.x + q * 256;          // 32 x 32 cells, row-major: coalesced reads of 128 bytes per row
+    const int r = cell >> 5, c = cell & 31;
+    const int row = I * kSymTile + r, col = J * kSymTile + c;
+    const uint32_t w = (row < rows && col < ld) ? enc[enc_index(row, col, ld)] : kInfWord;
+    dst[((r & 3) * 64 + (r >> 2) + 8 * (c >> 2)) * 4 + (c & 3)] = w;
+  }
 }
 
 }  // namespace topolow

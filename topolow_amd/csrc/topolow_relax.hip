@@ -30,6 +30,7 @@
 #include "relax_fold.h"
 #include "relax_gs.h"
 #include "relax_tilegs.h"
+#include "relax_symm.h"
 
 using namespace topolow;
 
@@ -263,6 +264,20 @@ struct topolow_session {
   DevBuf<double*> rsum_tab;            // every block's rank_sum / rank_cnt (self included)
   DevBuf<unsigned long long*> rcnt_tab;
   int n_ranks = 0, rank = 0;
+  // Symmetric sweep (relax_symm.h): one-stage iterations of a whole-matrix fp32 session.
+  struct SymState {
+    bool allowed = false;          // TOPOLOW_SYMMETRIC=1 (session creation)
+    bool ready = false;            // plan + tile-major copy built for the current block
+    int n32 = 0, tiles = 0, grid = 0, n_units = 0;
+    DevBuf<uint32_t> tenc;
+    DevBuf<float> rec[2];
+    int rec_cur = 0, rec_iter = -1;   // rec[rec_cur] holds the records of iteration rec_iter
+    DevBuf<float> rowpart, colpart;
+    DevBuf<SymUnit> units;
+    DevBuf<int> wave_first;
+    DevBuf<int2> row_units;
+  } sym;
+  int fused_parts = 0;             // partial sums the last ERR launch wrote (stage kernel: workgroups; sweep: units)
   // profiling (roofline accounting)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_stage, prof_stage_err, prof_check;   // _err: launches that also reduce the MAE
@@ -550,6 +565,7 @@ void download_positions(topolow_session* s, const void* src, double* host_colmaj
 }
 
 void compute_row_flags(topolow_session* s) {
+  s->sym.ready = false;   // the encoded block changed: the symmetric sweep's copy is rebuilt on first use
   s->rowflags.alloc(s->rows());
   DevBuf<unsigned long long> measured;
   measured.alloc(1);
@@ -647,6 +663,113 @@ void launch_tilegs_finite(topolow_session* s, const void* pos, int iter1) {
   HIP_TRY(hipGetLastError());
 }
 
+// ---- symmetric sweep (relax_symm.h) ----------------------------------------------------------
+// Which sessions take it: the whole matrix on one GPU (no row block, nothing to push), fp32 slab schedule, ndim
+// 2..6 (the register-tiled kernel keeps four rows' coordinates, constants and sums in VGPRs: 12 x ndim of them), at
+// least 2048 points.  Everything else -- and every multi-stage iteration -- stays on the row-owner stage kernel.
+template <int DIM> constexpr bool kSymDim = DIM >= 2 && DIM <= 6;
+constexpr int kSymMinPoints = 7168;   // below ~7000 points a resident wave gets fewer than 8 tiles and the row-owner sweep is faster (tests/study/symm_crossover.py)
+
+bool sym_eligible(const topolow_session* s) {
+  static const int min_n = [] { const char* e = getenv("TOPOLOW_SYMMETRIC_MIN_N"); return e ? atoi(e) : kSymMinPoints; }();
+  return s->sym.allowed && s->schedule == TOPOLOW_SCHEDULE_SLAB && s->precision == TOPOLOW_PRECISION_F32 &&
+         s->row_begin == 0 && s->row_end == s->n && s->n_push == 0 && s->dim >= 2 && s->dim <= 6 && s->n >= min_n &&
+         s->dim == s->udim && !(s->any_threshold && s->dim == 6);   // (the threshold-carrying ERR instance spills at 6)
+}
+
+template <int DIM>
+void sym_prepare(topolow_session* s) {
+  if constexpr (!kSymDim<DIM>) {
+    throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
+  } else {
+    auto& y = s->sym;
+    y.n32 = (s->n + kSymTile - 1) & ~(kSymTile - 1);
+    const int T = y.n32 / kSymTile;
+    y.tiles = (int)sym_tile_index(T - 1, T - 1, T) + 1;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    int occ = 1 << 30;   // the session's two instances (plain, ERR) share one plan: the smaller occupancy decides the grid
+    auto probe = [&](auto kern) {
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * kSymWaves, 0));
+      occ = std::min(occ, std::max(1, per_cu));
+    };
+    if (s->any_threshold) {
+      probe(&symm_sweep_kernel<DIM, true, false>);
+      probe(&symm_sweep_kernel<DIM, true, true>);
+    } else {
+      probe(&symm_sweep_kernel<DIM, false, false>);
+      probe(&symm_sweep_kernel<DIM, false, true>);
+    }
+    y.grid = occ * prop.multiProcessorCount;
+    const SymPlan plan = relax_symm_plan(y.n32, y.grid * kSymWaves);
+    y.n_units = (int)plan.units.size();
+    y.units.alloc(plan.units.size());
+    y.wave_first.alloc(plan.wave_first.size());
+    y.row_units.alloc(plan.row_units.size());
+    HIP_TRY(hipMemcpy(y.units.p, plan.units.data(), plan.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(y.wave_first.p, plan.wave_first.data(), plan.wave_first.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(y.row_units.p, plan.row_units.data(), plan.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
+    y.tenc.alloc((size_t)y.tiles * kSymTile * kSymTile);
+    hipLaunchKernelGGL(symm_tiles_kernel, dim3(y.tiles), dim3(256), 0, s->stream, s->enc.p, s->rows(), s->ld, y.tenc.p, T);
+    HIP_TRY(hipGetLastError());
+    constexpr int W = SymRec<DIM>::W;
+    for (auto& r : y.rec) r.alloc((size_t)y.n32 * W);
+    y.rowpart.alloc((size_t)y.n_units * kSymTile * DIM);
+    y.colpart.alloc((size_t)T * y.n32 * DIM);
+    if ((size_t)y.n_units > s->part_sum.n) {   // error partials: one per unit
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      HIP_TRY(hipStreamSynchronize(s->check_stream));
+      s->part_sum.alloc(y.n_units);
+      s->part_cnt.alloc(y.n_units);
+    }
+    y.rec_iter = -1;
+    y.ready = true;
+  }
+}
+
+// One one-stage iteration: records of this iteration (built from `pin` unless the previous iteration's apply left
+// them), sweep, apply into `pout` (and the next iteration's records).  err: the sweep also reduces the pending
+// check's MAE (positions read = that check's positions).
+template <int DIM>
+void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, double k, bool err) {
+  if constexpr (!kSymDim<DIM>) {
+    throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
+  } else {
+    auto& y = s->sym;
+    if (!y.ready) sym_prepare<DIM>(s);
+    ProfScope prof(s, err ? &s->prof_stage_err : &s->prof_stage);
+    const int T = y.n32 / kSymTile;
+    if (y.rec_iter != iter) {
+      for (int b = 0; b < 2; ++b)   // both buffers need the phantom records; the second one's points are overwritten by the apply
+        hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((y.n32 + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
+                           s->gplus.p, y.rec[b].p, s->n, y.n32, k, s->c_rep);
+      y.rec_cur = 0;
+    }
+    const float* rec = y.rec[y.rec_cur].p;
+    float* rec_next = y.rec[y.rec_cur ^ 1].p;
+    auto sweep = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec, y.units.p, y.wave_first.p,
+                         y.rowpart.p, y.colpart.p, y.n32, s->state.p, s->part_sum.p, s->part_cnt.p,
+                         s->block_cells / 2ull);
+    };
+    if (s->any_threshold) {
+      if (err) sweep(&symm_sweep_kernel<DIM, true, true>); else sweep(&symm_sweep_kernel<DIM, true, false>);
+    } else {
+      if (err) sweep(&symm_sweep_kernel<DIM, false, true>); else sweep(&symm_sweep_kernel<DIM, false, false>);
+    }
+    const double k_next = k * (1.0 - s->cooling);
+    hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(32 * kSymApplyParts), 0, s->stream, rec, rec_next, (float*)pout,
+                       s->gplus.p, y.rowpart.p, y.colpart.p, y.row_units.p, s->n, y.n32, k_next, s->c_rep, iter + 1,
+                       s->state.p);
+    HIP_TRY(hipGetLastError());
+    y.rec_cur ^= 1;
+    y.rec_iter = iter + 1;
+    if (err) s->fused_parts = y.n_units;
+    s->stage_launches += 1;
+  }
+}
+
 // One convergence check of the session's own loop.  error_pass = true: the separate pass over the block (or
 // the edge list) + the controller; false: the partials were written by the stage kernel just launched
 // (ERR launch), only the controller follows.  pc.beside: on the check stream, beside the next stages.
@@ -664,8 +787,7 @@ void launch_check(topolow_session* s, topolow_session::PendingCheck& pc, bool er
       TL_DISPATCH_DIM(s->dim, launch_edge_error, s, s->pos[pc.buf].p, s->state.p);
       launch_controller(s, s->pos[pc.buf].p, pc.iter1, pc.k_after);
     } else {
-      const int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
-      launch_controller(s, s->pos[pc.buf].p, pc.iter1, pc.k_after, s->part_sum.p, s->part_cnt.p, stage_blocks);
+      launch_controller(s, s->pos[pc.buf].p, pc.iter1, pc.k_after, s->part_sum.p, s->part_cnt.p, s->fused_parts);
     }
   }
   if (pc.beside) HIP_TRY(hipEventRecord(s->ev_check_done, check_on));
@@ -814,6 +936,8 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     s->serial_checks = serial != nullptr && serial[0] == '1';
     const char* fuse = getenv("TOPOLOW_FUSE_CHECKS");
     s->fuse_checks = !(fuse != nullptr && fuse[0] == '0');
+    const char* symm = getenv("TOPOLOW_SYMMETRIC");
+    s->sym.allowed = !(symm != nullptr && symm[0] == '0');   // TOPOLOW_SYMMETRIC=0: row-owner sweeps only
     s->enc.alloc((size_t)((s->rows() + kEncRowAlign - 1) / kEncRowAlign * kEncRowAlign) * s->ld);
     const size_t pos_bytes = (size_t)s->pos_rows() * s->dim * s->real_size();
     for (auto& b : s->pos) b.alloc(pos_bytes);
@@ -1108,6 +1232,7 @@ int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double 
     s->host_seen_stop = false;
     s->held = -1;
     s->pcheck.active = false;
+    s->sym.rec_iter = -1;
     s->began = true;
     RunState st;
     std::memset(&st, 0, sizeof st);
@@ -1142,6 +1267,12 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         const SlabGeom g = slab_geom(s->n, stages);
         const bool fuse_now = s->pcheck.active && g.n_stages == 1;
         if (s->pcheck.active && !fuse_now) flush_pending_check(s);
+        if (g.n_stages == 1 && sym_eligible(s)) {   // one sweep over the upper triangle moves both ends of every pair
+          int out = 0;
+          while (out == s->cur || out == s->held) ++out;
+          TL_DISPATCH_DIM(s->dim, sym_iteration, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host, fuse_now);
+          s->cur = out;
+        } else
         for (int slot = 0; slot < g.n_stages; ++slot) {
           const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
           int out = 0;   // a buffer that is neither the input nor the one a running check reads
@@ -1149,6 +1280,7 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
           TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[s->cur].p, s->pos[out].p, s->state.p, rg,
                           iter + 1, s->k_host, nullptr, 0, fuse_now);
           s->cur = out;
+          if (fuse_now) s->fused_parts = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
         }
         if (fuse_now) launch_check(s, s->pcheck, /*error_pass=*/false);
       }
