@@ -142,19 +142,14 @@ def run_single(args):
     slice_rates = K / np.mean(np.array(rotations), axis=0)       # per slice position, mean over rotations
 
     # ---- profiled pass over the same iterations: HIP events around every stage launch on the session stream ----
-    tail = 60                                                    # + one-stage iterations priced on their own
-    fresh(P * K + tail)
+    fresh(P * K)
     s.set_profiling(True)
     done = 0
     while done < P * K:
         done += s.enqueue(P * K - done)
-    fused_ms, fused_launches = s.profile_fused()     # launches that also reduce a check's MAE (subset of the next)
+    sym_ms, sym_iters, sym_err_ms, sym_err_iters = s.profile_symmetric()   # one-stage iterations: symmetric sweep + apply
+    fused_ms, fused_launches = s.profile_fused()     # row-owner launches that also reduce a check's MAE (subset of the next)
     stage_ms, stage_launches, check_ms, checks = s.profile()
-    done = 0
-    while done < tail:
-        done += s.enqueue(tail - done)
-    tail_fused_ms, tail_fused = s.profile_fused()
-    tail_ms, tail_launches, _cm, _cc = s.profile()
     s.set_profiling(False)
     s.sync()
 
@@ -168,9 +163,8 @@ def run_single(args):
                 break
             with open(os.path.join(ROOT, "profiles", prof)) as fh:
                 for name, vals in json.load(fh).items():
-                    # the plain instance (..., ANYTHR = false, ERR = false>), one-stage launches (profiles/README.md)
-                    if ("slab_stage_" in name and "<5, float" in name and "false, false> [one-stage launches]" in name
-                            and "hbm_traffic_bytes_per_launch" in vals):
+                    # sweep (plain instance) + apply of one iteration, summed by tools/summarize_profiles.py
+                    if name == "symmetric one-stage iteration (sweep + apply)" and "hbm_traffic_bytes_per_launch" in vals:
                         traffic = vals["hbm_traffic_bytes_per_launch"]
                         traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                        "FETCH_SIZE x2 on gfx950; measured by the commit that added the file, not "
@@ -182,29 +176,49 @@ def run_single(args):
 
     bytes_iter = s.bytes_per_iteration
     n_timed = P * K
-    stages_per_iter = stage_launches / n_timed
-    # the dominant kernel = the plain stage instance over the whole job (launches of 1/16, 1/2 and 1/1 of the
-    # matrix); the instance that also reduces a check's MAE (always a whole-matrix sweep) is priced next to it
+    sweeps = stage_launches + sym_iters + sym_err_iters          # launches that move points, per job
+    stages_per_iter = sweeps / n_timed
+    # Three kinds of sweep share the job: the row-owner stage kernel's launches over 1/16 or 1/2 of the columns
+    # (multi-stage iterations), and -- one-stage iterations -- either the symmetric sweep + apply (whole-matrix fp32
+    # sessions of this size: csrc/relax_symm.h) or the row-owner kernel's whole-matrix launch; each of the last two
+    # also comes in the form that reduces the previous check's MAE on its way.  All are priced with SURVEY.md
+    # section 8d's algorithmic bytes (4 N^2 + 8 N d + 4 N per iteration), whatever they physically read.
+    def priced(ms, launches, bytes_total, kernel, note):
+        if not launches:
+            return None
+        sec = ms * 1e-3 / launches
+        per = bytes_total / launches
+        return {"kernel": kernel, "launches": int(launches), "avg_launch_us": sec * 1e6,
+                "algorithmic_bytes_per_launch": per, "achieved": per / sec / 1e9,
+                "frac": per / sec / 1e9 / HBM_PEAK_GBPS, "note": note}
     plain_launches = stage_launches - fused_launches
-    plain_bytes = bytes_iter * n_timed - bytes_iter * fused_launches
-    bytes_per_launch = plain_bytes / max(plain_launches, 1)
-    avg_launch_s = (stage_ms - fused_ms) * 1e-3 / max(plain_launches, 1)
-    achieved = bytes_per_launch / avg_launch_s / 1e9
-    fused = None
-    if fused_launches:
-        f_s = fused_ms * 1e-3 / fused_launches
-        fused = {"kernel": "slab_stage_pipe_kernel<5,float,...,ERR=true>", "launches": int(fused_launches),
-                 "avg_launch_us": f_s * 1e6, "achieved": bytes_iter / f_s / 1e9,
-                 "frac": bytes_iter / f_s / 1e9 / HBM_PEAK_GBPS,
-                 "note": "a one-stage iteration that follows a checked iteration: the same sweep also reduces that "
-                         "check's MAE (no separate 2 N^2-byte pass); its check_us is the controller alone"}
-    one_stage = None
-    if tail_launches == tail and tail_launches > tail_fused:
-        o_s = (tail_ms - tail_fused_ms) * 1e-3 / (tail_launches - tail_fused)
-        one_stage = {"launches": int(tail_launches - tail_fused), "avg_launch_us": o_s * 1e6,
-                     "achieved": bytes_iter / o_s / 1e9, "frac": bytes_iter / o_s / 1e9 / HBM_PEAK_GBPS,
-                     "note": f"the plain instance over the {tail} iterations after the job (one whole-matrix sweep "
-                             "each): the launch the PMC traffic figure refers to"}
+    parts = {
+        "symmetric_sweep": priced(sym_ms, sym_iters, bytes_iter * sym_iters,
+                                  "symm_sweep_kernel<5> + symm_apply_kernel<5>",
+                                  "one-stage iteration: every unordered pair once from the tile-major upper triangle, "
+                                  "then the fixed-order sum of the partials; reads ~half the algorithmic bytes"),
+        "symmetric_sweep_with_check": priced(sym_err_ms, sym_err_iters, bytes_iter * sym_err_iters,
+                                             "symm_sweep_kernel<5,ERR> + symm_apply_kernel<5>",
+                                             "the same, the sweep also reducing the previous check's MAE (no separate "
+                                             "2 N^2-byte pass); check_us is then the controller alone"),
+        "stage_kernel": priced(stage_ms - fused_ms, plain_launches, bytes_iter * (n_timed - sym_iters - sym_err_iters
+                                                                                  - fused_launches),
+                               "slab_stage_pipe_kernel<5,float>",
+                               "row-owner launches: 1/16 of the columns while the layout unfolds, 1/2 while k > 2.5 "
+                               "(and whole-matrix ones where the symmetric sweep does not apply)"),
+        "stage_kernel_with_check": priced(fused_ms, fused_launches, bytes_iter * fused_launches,
+                                          "slab_stage_pipe_kernel<5,float,...,ERR=true>", "row-owner whole-matrix "
+                                          "launch that also reduces the previous check's MAE"),
+    }
+    parts = {k_: v for k_, v in parts.items() if v}
+    dominant = max(parts.values(), key=lambda v: v["launches"] * v["avg_launch_us"])
+    job_ms = stage_ms + sym_ms + sym_err_ms
+    job = {"launches": int(sweeps), "total_ms": job_ms, "achieved": bytes_iter * n_timed / (job_ms * 1e-3) / 1e9,
+           "frac": bytes_iter * n_timed / (job_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "note": "all sweeps of the job together: its algorithmic bytes / their summed durations"}
+    achieved = dominant["achieved"]
+    avg_launch_s = dominant["avg_launch_us"] * 1e-6
+    bytes_per_launch = dominant["algorithmic_bytes_per_launch"]
 
     out = {
         "metric": "relaxation iterations/sec (NxN pairs)",
@@ -234,15 +248,16 @@ def run_single(args):
                            "schedule: the first slices hold the 16- and 2-stage iterations"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "traffic_refers_to": {"launch": "a one-stage launch (the whole matrix in one sweep)",
+                     "traffic_refers_to": {"launch": "one one-stage iteration of the dominant kind",
                                            "algorithmic_bytes": bytes_iter,
-                                           "ratio": (traffic / bytes_iter) if traffic else None},
-                     "kernel": "slab_stage_pipe_kernel<5,float>", "avg_launch_us": avg_launch_s * 1e6,
-                     "launches": int(plain_launches), "fused_check_instance": fused, "one_stage_launch": one_stage,
-                     "timing": "HIP events on the session stream around every stage launch, in a separate "
-                               "pass over the same iterations (inside the timed slices the events themselves "
-                               "would cost throughput); rocprofv3 kernel-trace mean: profiles/",
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                                           "ratio": (traffic / bytes_iter) if traffic else None,
+                                           "physical_GBps": (traffic / avg_launch_s / 1e9) if traffic else None},
+                     "kernel": dominant["kernel"], "avg_launch_us": avg_launch_s * 1e6,
+                     "launches": dominant["launches"], "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "dominant_note": dominant["note"], "by_kind": parts, "job": job,
+                     "timing": "HIP events on the session stream around every sweep (a symmetric sweep and its apply "
+                               "as one), in a separate pass over the same iterations (inside the timed slices the "
+                               "events themselves would cost throughput); rocprofv3 kernel-trace means: profiles/",
                      "check_us": (check_ms * 1e3 / checks) if checks else None},
         "final_mae": res.final_mae,
         "final_mae_iteration": res.iterations,

@@ -301,6 +301,10 @@ int topolow_session_set_profiling(topolow_session* s, int32_t enable);
  * not reset anything: ask before topolow_session_profile, whose stage figures include these launches. */
 int topolow_session_profile_fused(topolow_session* s, double* fused_ms, int64_t* fused_launches, char* errbuf,
                                   size_t errlen);
+/* Iterations that ran as a symmetric sweep + apply (csrc/relax_symm.h) since profiling was enabled: their HIP-event
+ * time, the plain ones and those whose sweep also reduced a check's MAE apart.  Not included in the two calls above. */
+int topolow_session_profile_symmetric(topolow_session* s, double* plain_ms, int64_t* plain_iterations, double* fused_ms,
+                                      int64_t* fused_iterations, char* errbuf, size_t errlen);
 int topolow_session_profile(topolow_session* s, double* stage_ms, int64_t* stage_launches,
                             double* check_ms, int64_t* checks, char* errbuf, size_t errlen);
 /* external != 0: the session launches on the caller's stream `hip_stream` (a hipStream_t; NULL

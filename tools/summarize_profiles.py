@@ -22,7 +22,7 @@ if ks:
 for f in glob.glob(prefix + "_kt/*/*_kernel_trace.csv"):
     rows = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "slab_stage_" in r["Kernel_Name"]:
+        if "slab_stage_" in r["Kernel_Name"] or "symm_" in r["Kernel_Name"]:
             rows[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     out = {}
     for k, v in rows.items():
@@ -73,6 +73,18 @@ for k, v in summary.items():
         v["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024
     if "hbm_read_bytes_per_launch" in v and "hbm_write_bytes_per_launch" in v:
         v["hbm_traffic_bytes_per_launch"] = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+# one symmetric one-stage iteration = its sweep (plain instance) + its apply: the entry bench.py's roofline.traffic reads
+sw = [k for k in summary if "symm_sweep_kernel<5, false, false>" in k]
+ap = [k for k in summary if "symm_apply_kernel<5>" in k]
+if sw and ap and "hbm_traffic_bytes_per_launch" in summary[sw[0]] and "hbm_traffic_bytes_per_launch" in summary[ap[0]]:
+    a, b = summary[sw[0]], summary[ap[0]]
+    both = {}
+    for key in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_traffic_bytes_per_launch",
+                "mean_duration_us_fetch", "mean_duration_us_write", "mean_duration_us_sq"):
+        if key in a and key in b:
+            both[key] = a[key] + b[key]
+    both["parts"] = [sw[0], ap[0]]
+    summary["symmetric one-stage iteration (sweep + apply)"] = both
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 for k, v in summary.items():
-    print(k[:60], {c: round(x, 1) for c, x in v.items() if "bytes" in c or "duration" in c})
+    print(k[:60], {c: round(x, 1) for c, x in v.items() if ("bytes" in c or "duration" in c) and not isinstance(x, list)})

@@ -149,6 +149,9 @@ def load() -> C.CDLL:
     i64p = C.POINTER(C.c_int64)
     lib.topolow_cv_fold.argtypes = [C.POINTER(TopolowCellList), i64p, C.c_int64, C.c_int32, C.c_int32, ip, ip,
                                     ip, ip, dp, ip, i64p, ip, ip, dp, i64p, dp]
+    lib.topolow_session_profile_symmetric.restype = C.c_int
+    lib.topolow_session_profile_symmetric.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                                      C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
     lib.topolow_session_profile_fused.restype = C.c_int
     lib.topolow_session_profile_fused.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_char_p,
                                                   C.c_size_t]
@@ -797,6 +800,15 @@ class Session:
         _check(self.lib.topolow_session_profile(self._h, C.byref(sm), C.byref(sl), C.byref(cm),
                                                 C.byref(cl), self._err, len(self._err)), self._err)
         return float(sm.value), int(sl.value), float(cm.value), int(cl.value)
+
+    def profile_symmetric(self):
+        """(plain_ms, plain_iterations, fused_ms, fused_iterations) of the iterations that ran as a symmetric sweep +
+        apply since profiling was enabled (not part of profile() / profile_fused())."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        na, nb = C.c_int64(0), C.c_int64(0)
+        _check(self.lib.topolow_session_profile_symmetric(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb),
+                                                          self._err, len(self._err)), self._err)
+        return float(a.value), int(na.value), float(b.value), int(nb.value)
 
     def profile_fused(self):
         """(ms, launches) of the stage launches that also reduced a check's MAE; ask before profile()."""

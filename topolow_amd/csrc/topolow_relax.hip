@@ -281,6 +281,7 @@ struct topolow_session {
   // profiling (roofline accounting)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_stage, prof_stage_err, prof_check;   // _err: launches that also reduce the MAE
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_sym, prof_sym_err;                   // symmetric sweep + apply of one iteration
 
   size_t real_size() const { return precision == TOPOLOW_PRECISION_F64 ? 8 : 4; }
   int rows() const { return row_end - row_begin; }
@@ -290,6 +291,8 @@ struct topolow_session {
     for (auto& pr : prof_stage) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : prof_stage_err) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : prof_check) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : prof_sym) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : prof_sym_err) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (mailbox) (void)hipHostFree(mailbox);
@@ -738,7 +741,7 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
   } else {
     auto& y = s->sym;
     if (!y.ready) sym_prepare<DIM>(s);
-    ProfScope prof(s, err ? &s->prof_stage_err : &s->prof_stage);
+    ProfScope prof(s, err ? &s->prof_sym_err : &s->prof_sym);
     const int T = y.n32 / kSymTile;
     if (y.rec_iter != iter) {
       for (int b = 0; b < 2; ++b)   // both buffers need the phantom records; the second one's points are overwritten by the apply
@@ -1437,6 +1440,31 @@ int topolow_session_profile_fused(topolow_session* s, double* fused_ms, int64_t*
     }
     if (fused_ms) *fused_ms = total;
     if (fused_launches) *fused_launches = (int64_t)s->prof_stage_err.size();
+  });
+}
+
+int topolow_session_profile_symmetric(topolow_session* s, double* plain_ms, int64_t* plain_iterations, double* fused_ms,
+                                      int64_t* fused_iterations, char* errbuf, size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    flush_pending_check(s);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->check_stream));
+    auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double* ms, int64_t* cnt) {
+      double total = 0.0;
+      for (auto& pr : v) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) total += t;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+      }
+      if (ms) *ms = total;
+      if (cnt) *cnt = (int64_t)v.size();
+      v.clear();
+    };
+    drain(s->prof_sym, plain_ms, plain_iterations);
+    drain(s->prof_sym_err, fused_ms, fused_iterations);
   });
 }
 
