@@ -46,8 +46,8 @@ struct SymUnit {
 // The sweep reads the targets from a TILE-MAJOR copy of the upper triangle: tile (I, J), J >= I, is 4 KB at tile index
 // I T - I (I - 1) / 2 + (J - I), T = n32 / 32, so a unit is one contiguous run; inside a tile the word of
 // (row 4a + j, column 4b + q) sits at ((j * 64 + a + 8 b) * 4 + q): each of a wave's four loads covers 1 KB.  (Read from
-// the row-major block the same tile is 32 segments of 128 bytes, rows ld * 4 bytes apart: 69 instead of .. us per
-// sweep at N = 10 000 whatever the number of waves per SIMD -- the DRAM pages, not the arithmetic, set the pace.)
+// the row-major block the same tile is 32 segments of 128 bytes, rows ld * 4 bytes apart: 68.6 instead of 64.8 us per
+// sweep at N = 10 000.)
 inline long long sym_tile_index(int I, int J, int T) { return (long long)I * T - (long long)I * (I - 1) / 2 + (J - I); }
 inline size_t sym_word_in_tile(int r, int c) { return (size_t)(((r & 3) * 64 + (r >> 2) + 8 * (c >> 2)) * 4 + (c & 3)); }
 
