@@ -45,7 +45,12 @@ extern "C" {
  *         mean +- max(3 sd, 1 %) on every pinned problem (N = 1500 ... 10 000, ndim 2 ... 5, thresholds,
  *         relative_epsilon 1e-4 ... 1e-10); the MAE it reports is the reference's edge MAE of the positions
  *         it returns to 2e-5; stop iteration within max(3 sd, 10 %) of the oracle's except on 2-D data
- *         (+55 %, same MAE).
+ *         (+55 %, same MAE).  Iterations that are ONE stage (k <= 2.5) of a whole-matrix fp32 session with
+ *         ndim 2..6 and >= 7168 points run as a symmetric sweep (csrc/relax_symm.h): the same update -- every
+ *         point moved by the sum of its own halves of all its pairs at the positions the previous iteration
+ *         left -- with each pair's distance and factor computed once; it differs from the row-owner sweep in
+ *         fp32 summation order only (positions to 2e-6 per iteration, same stop iteration and final MAE to
+ *         1e-6 on whole runs: tests/test_gpu_symmetric.py; TOPOLOW_SYMMETRIC=0 switches it off).
  * The deterministic pieces -- controller, cooling, error rule, guards, messages -- are exact. */
 
 /* Schedules (topolow_options.schedule). */
