@@ -731,6 +731,23 @@ void sym_prepare(topolow_session* s) {
   }
 }
 
+// Builds the sweep's buffers on first use.  They cost device memory (half the encoded block again, plus the
+// partials): if the device cannot give it, the session simply keeps the row-owner sweep.
+bool sym_available(topolow_session* s) {
+  if (s->sym.ready) return true;
+  try {
+    TL_DISPATCH_DIM(s->dim, sym_prepare, s);
+  } catch (const HipError&) {
+    (void)hipGetLastError();
+    auto& y = s->sym;
+    y.tenc.release(); y.rec[0].release(); y.rec[1].release(); y.rowpart.release(); y.colpart.release();
+    y.units.release(); y.wave_first.release(); y.row_units.release();
+    y.ready = false;
+    y.allowed = false;
+  }
+  return s->sym.ready;
+}
+
 // One one-stage iteration: records of this iteration (built from `pin` unless the previous iteration's apply left
 // them), sweep, apply into `pout` (and the next iteration's records).  err: the sweep also reduces the pending
 // check's MAE (positions read = that check's positions).
@@ -740,7 +757,6 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
     throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
   } else {
     auto& y = s->sym;
-    if (!y.ready) sym_prepare<DIM>(s);
     ProfScope prof(s, err ? &s->prof_sym_err : &s->prof_sym);
     const int T = y.n32 / kSymTile;
     if (y.rec_iter != iter) {
@@ -1270,7 +1286,7 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         const SlabGeom g = slab_geom(s->n, stages);
         const bool fuse_now = s->pcheck.active && g.n_stages == 1;
         if (s->pcheck.active && !fuse_now) flush_pending_check(s);
-        if (g.n_stages == 1 && sym_eligible(s)) {   // one sweep over the upper triangle moves both ends of every pair
+        if (g.n_stages == 1 && sym_eligible(s) && sym_available(s)) {   // one sweep over the upper triangle moves both ends of every pair
           int out = 0;
           while (out == s->cur || out == s->held) ++out;
           TL_DISPATCH_DIM(s->dim, sym_iteration, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host, fuse_now);
