@@ -172,10 +172,17 @@ inline void sharded_worker(ShardedRun& R, int r) {
       const SlabRanges rg = slab_ranges(geo, lead->seed, iter, slot);
       for (int b : G.blocks) {
         topolow_session* s = R.ss[b];
-        TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[cur].p, s->pos[(cur + 1) % 3].p, s->state.p, rg, iter + 1, k,
-                        s->push_tab[(cur + 1) % 3].p, s->n_push, fuse_now);
+        int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
+        if (R.P == 1 && geo.n_stages == 1 && sym_eligible(s) && sym_available(s)) {
+          // ONE block = the whole matrix: a one-stage iteration may run as the symmetric sweep (relax_symm.h), as in
+          // the session's own loop; its error partials are one per (unit)
+          TL_DISPATCH_DIM(s->dim, sym_iteration, s, s->pos[cur].p, s->pos[(cur + 1) % 3].p, iter, k, fuse_now);
+          stage_blocks = s->sym.n_units;
+        } else {
+          TL_DISPATCH_DIM(s->dim, launch_stage, s, s->pos[cur].p, s->pos[(cur + 1) % 3].p, s->state.p, rg, iter + 1, k,
+                          s->push_tab[(cur + 1) % 3].p, s->n_push, fuse_now);
+        }
         if (fuse_now) {   // the sweep's per-workgroup partials -> this block's slot of every rank table
-          const int stage_blocks = (s->rows() + CfgProd::ROWS - 1) / CfgProd::ROWS;
           ProfScope prof(s, &s->prof_check);
           hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
                              stage_blocks, s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, tab + s->rank, s->state.p);

@@ -1929,7 +1929,10 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
             double sm = 0, cm = 0;
             int64_t sl = 0, cl = 0;
             (void)topolow_session_profile(R.ss[b], &sm, &sl, &cm, &cl, nullptr, 0);
-            stats->stage_kernel_seconds += sm * 1e-3;
+            double ya = 0, yb = 0;    // a single block's one-stage iterations may have run as symmetric sweeps
+            int64_t na = 0, nb = 0;
+            (void)topolow_session_profile_symmetric(R.ss[b], &ya, &na, &yb, &nb, nullptr, 0);
+            stats->stage_kernel_seconds += (sm + ya + yb) * 1e-3;
             stats->check_kernel_seconds += cm * 1e-3;
           }
         }

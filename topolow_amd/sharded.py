@@ -587,9 +587,12 @@ def _bench_sharded_native(args, devices):
                    "note": "each pass = one topolow_sessions_run_sharded call of W + K iterations; the library drains "
                            "the GPUs after W and times the remaining K itself"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "slab_stage_pipe_kernel<3,float>",
+                     "traffic": None,
+                     "kernel": ("slab_stage_pipe_kernel<3,float> (multi-stage iterations) + symm_sweep_kernel<3> / "
+                                "symm_apply_kernel<3> (one-stage iterations: ONE block is the whole matrix)"
+                                if len(rows) == 1 else "slab_stage_pipe_kernel<3,float>"),
                      "note": f"first GPU ({n_group0} row block(s)): algorithmic bytes of its row blocks / summed "
-                             "durations of their stage kernels (HIP events, profiled pass over W + K iterations)"},
+                             "durations of their sweeps (HIP events, profiled pass over W + K iterations)"},
         "breakdown_ms_per_iteration": {
             "note": "profiled pass, W + K iterations incl. the 16-stage unfolding phase, first GPU",
             "loop_wall": 1e3 * i["loop_seconds"] * per_iter,
