@@ -81,3 +81,30 @@ def test_symmetric_sweep_reports_a_diverging_run():
     for sym in (False, True):
         with pytest.raises(_native.NativeError, match="Numerical instability"):
             session_run(call, n, 3, sym, 200, 500.0, stages=1)
+
+
+def test_single_block_engine_run_takes_the_symmetric_sweep_too():
+    """topolow_sessions_run_sharded with ONE block (the whole matrix) and the session's own loop run the same
+    kernels in the same order: bit-identical positions, same checks."""
+    n, dim = 7205, 3
+    call, _ = pp.random_problem(n, dim, 0.7, seed=21, n_iter=10, k0=1.5)
+
+    def make():
+        s = _native.Session(n, dim, precision="f32")
+        s.load_coo(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.degrees)
+        s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        return s
+    s = make()
+    s.set_positions(call.initial_positions)
+    s.begin(40, 2.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 5, 0)
+    s.run()
+    s.sync()
+    a, ta = s.finish(), s.check_trace()
+    s.close()
+    s = make()
+    b = _native.run_sharded([s], call.initial_positions, 40, 2.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 5, 0)
+    tb = s.check_trace()
+    s.close()
+    assert np.array_equal(a.positions, b.positions)
+    assert a.iterations == b.iterations and b.final_mae == pytest.approx(a.final_mae, rel=1e-12)
+    assert np.allclose(ta[:, 1], tb[:, 1], rtol=1e-12)
