@@ -209,6 +209,24 @@ int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_
                     int64_t* n_edges, int32_t* holdout_i, int32_t* holdout_j, double* holdout_truth,
                     int64_t* n_holdout, double* numeric_max);
 
+/* A whole cross-validation sweep in one call (the consumer of the hot path: the reference's likelihood_function,
+ * R/adaptive_sampling.R:2552-2726, folds x parameter sets times).  Fold f holds out the cells picks[picks_offset[f] ..
+ * picks_offset[f + 1]) (linear column-major indices, as topolow_cv_fold) and runs with ndim[f], k0[f], ...; its start
+ * positions are the reference's random walk (R/core.R:407-415) built from unit_draws[draws_offset[f] ..], the
+ * ndim[f] x (n - 1) uniform(0, 1) numbers, row-major, that the caller drew at this point of its stream.  The folds'
+ * problems are built on host threads and relaxed as ONE batch (topolow_optimize_layout_exact_batch); per fold only
+ * the out-of-sample score comes back: sum |truth - distance| and count over its held-out numeric cells, the best
+ * iteration and the converged flag; error_code[f] = TOPOLOW_ERR_BAD_ARGUMENT for a fold without valid measurements,
+ * TOPOLOW_ERR_NONFINITE for a diverged one. */
+int topolow_cv_sweep(const topolow_cell_list* cells, int32_t named, int32_t preserve_order, int32_t n_folds,
+                     const int32_t* ndim, const double* k0, const double* cooling_rate, const double* c_repulsion,
+                     const int64_t* picks, const int64_t* picks_offset, const double* unit_draws,
+                     const int64_t* draws_offset, const uint64_t* seeds, int32_t n_iter, double relative_epsilon,
+                     int32_t convergence_window, int32_t convergence_check_freq, int32_t precision, int32_t device,
+                     double* holdout_sum_abs, int64_t* holdout_count, int32_t* iterations, int32_t* converged,
+                     int32_t* error_code, double* device_seconds, char* errbuf, size_t errlen);
+
+
 /* Replaces `as.matrix(stats::dist(positions))` (reference R/core.R:474):
  * positions n x ndim float64 column-major (host) -> est_distances n x n float64 (host). */
 int topolow_est_distances(const double* positions, int32_t n, int32_t ndim,

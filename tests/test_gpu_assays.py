@@ -123,6 +123,14 @@ def test_sparse_cv_path_equals_the_dense_sequence(monkeypatch):
         assert y["NLL"] == pytest.approx(x["NLL"], rel=1e-12)
         assert y["mean_iter"] == x["mean_iter"] and y["pct_converged"] == x["pct_converged"]
     assert np.isnan(a[2]["Holdout_MAE"]) and np.isnan(b[2]["Holdout_MAE"])
+    # ... and the sweep as ONE library call (topolow_cv_sweep, the default) equals the sweep that builds a call object per
+    # fold here: same draws from the stream, same seeds, the same numbers to the last bit, the stream left in the same place
+    r1, r2 = np.random.default_rng(9), np.random.default_rng(9)
+    c, _, nc = cv.likelihood_sweep(hv, sets, 300, 1e-4, folds=5, rng=r1, path="sparse-calls")
+    d, _, nd = cv.likelihood_sweep(hv, sets, 300, 1e-4, folds=5, rng=r2, path="sparse")
+    assert nc == nd == 10 and r1.uniform() == r2.uniform()
+    for x, y in zip(c[:2], d[:2]):
+        assert x == y
     # the edge list standing for the matrix, on the dense-matrix kernel too (matrix rebuilt from it)
     call = core.prepare_layout_call(hv, 3, 120, 4.0, 0.03, 0.001, 1e-4, 5, None, False, 3, False,
                                     np.random.default_rng(5))

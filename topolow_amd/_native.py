@@ -149,6 +149,11 @@ def load() -> C.CDLL:
     i64p = C.POINTER(C.c_int64)
     lib.topolow_cv_fold.argtypes = [C.POINTER(TopolowCellList), i64p, C.c_int64, C.c_int32, C.c_int32, ip, ip,
                                     ip, ip, dp, ip, i64p, ip, ip, dp, i64p, dp]
+    u64p = C.POINTER(C.c_uint64)
+    lib.topolow_cv_sweep.restype = C.c_int
+    lib.topolow_cv_sweep.argtypes = [C.POINTER(TopolowCellList), C.c_int32, C.c_int32, C.c_int32, ip, dp, dp, dp, i64p, i64p,
+                                     dp, i64p, u64p, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     dp, i64p, ip, ip, ip, dp, C.c_char_p, C.c_size_t]
     lib.topolow_session_profile_symmetric.restype = C.c_int
     lib.topolow_session_profile_symmetric.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                                       C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
@@ -488,6 +493,41 @@ def cv_fold(cells: CellList, picks, preserve_order: bool, named: bool):
     e, h = int(ne.value), int(nh.value)
     return (None if order[0] < 0 else order.astype(np.int64), deg, ei[:e].copy(), ej[:e].copy(), ed[:e].copy(),
             et[:e].copy(), hi[:h].copy(), hj[:h].copy(), ht[:h].copy(), float(vmax.value))
+
+
+def cv_sweep(cells: CellList, named: bool, preserve_order: bool, ndims, k0s, cooling_rates, c_repulsions, picks, unit_draws,
+             seeds, n_iter: int, relative_epsilon: float, convergence_window: int = 5, convergence_check_freq: int = 3,
+             precision: str = "f64", device: int = -1):
+    """All folds of a CV sweep in one library call (topolow_cv_sweep): fold f holds out the cells picks[f] and starts
+    from the random walk built from unit_draws[f] ((ndim, n - 1) uniform(0, 1) numbers).  Returns
+    (holdout_sum_abs, holdout_count, iterations, converged, error_code) arrays and the device seconds."""
+    lib = load()
+    nf = len(picks)
+    nd = np.ascontiguousarray(ndims, dtype=np.int32)
+    k0 = np.ascontiguousarray(k0s, dtype=np.float64)
+    cr = np.ascontiguousarray(cooling_rates, dtype=np.float64)
+    cp = np.ascontiguousarray(c_repulsions, dtype=np.float64)
+    p_off = np.zeros(nf + 1, dtype=np.int64)
+    d_off = np.zeros(nf + 1, dtype=np.int64)
+    if nf:
+        np.cumsum([len(p) for p in picks], out=p_off[1:])
+        np.cumsum([u.size for u in unit_draws], out=d_off[1:])
+    p_all = np.ascontiguousarray(np.concatenate(picks) if nf else np.zeros(0), dtype=np.int64)
+    d_all = np.ascontiguousarray(np.concatenate([np.ravel(u) for u in unit_draws]) if nf else np.zeros(0), dtype=np.float64)
+    sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+    hsum, hcnt = np.zeros(nf, np.float64), np.zeros(nf, np.int64)
+    its, conv, ec = np.zeros(nf, np.int32), np.zeros(nf, np.int32), np.zeros(nf, np.int32)
+    secs = C.c_double(0.0)
+    err = C.create_string_buffer(512)
+    i64 = C.POINTER(C.c_int64)
+    rc = lib.topolow_cv_sweep(C.byref(cells.c), int(bool(named)), int(bool(preserve_order)), nf, _ip(nd), _dp(k0), _dp(cr),
+                              _dp(cp), p_all.ctypes.data_as(i64), p_off.ctypes.data_as(i64), _dp(d_all),
+                              d_off.ctypes.data_as(i64), sd.ctypes.data_as(C.POINTER(C.c_uint64)), int(n_iter),
+                              float(relative_epsilon), int(convergence_window), int(convergence_check_freq),
+                              _PRECISIONS[precision], int(device), _dp(hsum), hcnt.ctypes.data_as(i64), _ip(its), _ip(conv),
+                              _ip(ec), C.byref(secs), err, len(err))
+    _check(rc, err)
+    return hsum, hcnt, its, conv, ec, float(secs.value)
 
 
 def shard_rows(n: int, blocks: int):

@@ -1763,6 +1763,101 @@ int topolow_cv_fold(const topolow_cell_list* cells, const int64_t* picks, int64_
   }
 }
 
+// All folds of a cross-validation sweep in ONE call: the folds' problems are built side by side on host threads
+// (fold_problem; start positions from the caller's unit draws with NumPy's / R's arithmetic: a random walk whose
+// steps are uniform(0, 2 max / n), R/core.R:407-415) and relaxed as one batch; only the per-fold scores come back.
+int topolow_cv_sweep(const topolow_cell_list* cells, int32_t named, int32_t preserve_order, int32_t n_folds,
+                     const int32_t* ndim, const double* k0, const double* cooling_rate, const double* c_repulsion,
+                     const int64_t* picks, const int64_t* picks_offset, const double* unit_draws,
+                     const int64_t* draws_offset, const uint64_t* seeds, int32_t n_iter, double relative_epsilon,
+                     int32_t convergence_window, int32_t convergence_check_freq, int32_t precision, int32_t device,
+                     double* holdout_sum_abs, int64_t* holdout_count, int32_t* iterations, int32_t* converged,
+                     int32_t* error_code, double* device_seconds, char* errbuf, size_t errlen) {
+  if (!cells || n_folds < 0 || (n_folds > 0 && (!ndim || !k0 || !cooling_rate || !c_repulsion || !picks_offset ||
+      !unit_draws || !draws_offset || !seeds || !holdout_sum_abs || !holdout_count || !iterations || !converged ||
+      !error_code)))
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (device_seconds) *device_seconds = 0.0;
+  if (n_folds == 0) return TOPOLOW_OK;
+  const int n = cells->n;
+  const size_t m = (size_t)cells->n_cells;
+  struct Fold {
+    std::vector<int32_t> order, deg, ei, ej, et, hi, hj;
+    std::vector<double> ed, ht, pos, out;
+    int64_t ne = 0, nh = 0;
+    int rc = TOPOLOW_OK;
+  };
+  std::vector<Fold> F((size_t)n_folds);
+  try {
+    gs_parallel_for(n_folds, [&](int f) {
+      Fold& x = F[(size_t)f];
+      x.order.resize(n); x.deg.resize(n);
+      x.ei.resize(m); x.ej.resize(m); x.et.resize(m); x.ed.resize(m);
+      x.hi.resize(m); x.hj.resize(m); x.ht.resize(m);
+      double vmax = 0.0;
+      x.rc = fold_problem(cells, picks + picks_offset[f], picks_offset[f + 1] - picks_offset[f], preserve_order, named,
+                          x.order.data(), x.deg.data(), x.ei.data(), x.ej.data(), x.ed.data(), x.et.data(), &x.ne,
+                          x.hi.data(), x.hj.data(), x.ht.data(), &x.nh, &vmax);
+      if (x.rc == TOPOLOW_OK && (x.ne == 0 || !(vmax == vmax))) x.rc = TOPOLOW_ERR_BAD_ARGUMENT;   // no valid measurements
+      if (x.rc != TOPOLOW_OK) return;
+      const int d_ = ndim[f];
+      if (d_ < 1 || draws_offset[f + 1] - draws_offset[f] != (int64_t)d_ * (n - 1)) { x.rc = TOPOLOW_ERR_BAD_ARGUMENT; return; }
+      const double* u = unit_draws + draws_offset[f];             // (ndim, n - 1), row-major
+      const double step = vmax / (double)n;
+      x.pos.assign((size_t)n * d_, 0.0);                          // column-major n x ndim
+      x.out.assign((size_t)n * d_, 0.0);
+      for (int d = 0; d < d_; ++d) {
+        double acc = 0.0;
+        for (int i = 1; i < n; ++i) {
+          const double st_ = 0.0 + (2.0 * step - 0.0) * u[(size_t)d * (n - 1) + (i - 1)];   // Generator.uniform's arithmetic
+          acc = i == 1 ? st_ : acc + st_;                         // cumsum
+          x.pos[(size_t)i + (size_t)d * n] = acc;
+        }
+      }
+    });
+  } catch (const GsHipError& e) {
+    set_err(errbuf, errlen, "%s", e.msg.c_str());
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    set_err(errbuf, errlen, "out of host memory");
+    return TOPOLOW_ERR_HIP;
+  }
+  std::vector<topolow_problem> P;
+  std::vector<topolow_result> R;
+  std::vector<int> idx;
+  for (int f = 0; f < n_folds; ++f) {
+    Fold& x = F[(size_t)f];
+    holdout_sum_abs[f] = 0.0; holdout_count[f] = 0; iterations[f] = 0; converged[f] = 0;
+    error_code[f] = x.rc;
+    if (x.rc != TOPOLOW_OK) continue;
+    topolow_problem p;
+    std::memset(&p, 0, sizeof p);
+    p.initial_positions = x.pos.data();
+    p.degrees = x.deg.data();
+    p.edge_i = x.ei.data(); p.edge_j = x.ej.data(); p.edge_dist = x.ed.data(); p.edge_thresh = x.et.data();
+    p.n_edges = x.ne; p.n = n; p.ndim = ndim[f]; p.n_iter = n_iter;
+    p.convergence_window = convergence_window; p.convergence_check_freq = convergence_check_freq;
+    p.k0 = k0[f]; p.cooling_rate = cooling_rate[f]; p.c_repulsion = c_repulsion[f]; p.relative_epsilon = relative_epsilon;
+    p.seed = seeds[f];
+    if (x.nh > 0) { p.holdout_i = x.hi.data(); p.holdout_j = x.hj.data(); p.holdout_truth = x.ht.data(); p.n_holdout = x.nh; }
+    topolow_result r;
+    std::memset(&r, 0, sizeof r);
+    r.positions_out = x.out.data();
+    P.push_back(p); R.push_back(r); idx.push_back(f);
+  }
+  if (P.empty()) return TOPOLOW_OK;
+  const int rc = topolow_optimize_layout_exact_batch(P.data(), R.data(), (int32_t)P.size(), precision, device, device_seconds,
+                                                     errbuf, errlen);
+  if (rc != TOPOLOW_OK) return rc;
+  for (size_t q = 0; q < idx.size(); ++q) {
+    const int f = idx[q];
+    error_code[f] = R[q].error_code;
+    holdout_sum_abs[f] = R[q].holdout_sum_abs; holdout_count[f] = R[q].holdout_count;
+    iterations[f] = R[q].iterations; converged[f] = R[q].converged;
+  }
+  return TOPOLOW_OK;
+}
+
 // rows [row_begin, row_end) of as.matrix(dist(positions)): out is (row_end - row_begin) x n, row-major.
 // Device memory is bounded: the rows are produced in tiles of at most 256 MB.
 int topolow_est_distances_rows(const double* positions, int32_t n, int32_t ndim, int32_t row_begin,

@@ -323,6 +323,61 @@ def build_fold_calls(m, builder, param_sets, folds, rng, mapping_max_iter, relat
     return calls, owners, inputs, holds
 
 
+def _pooled(per_set):
+    out = []
+    for rows in per_set:
+        rows = [r for r in rows if r["n_samples"] > 0]
+        if not rows:
+            out.append(dict(Holdout_MAE=math.nan, NLL=math.nan, mean_iter=math.nan, pct_converged=math.nan))
+            continue
+        total = sum(r["n_samples"] for r in rows)
+        tot_err = sum(r["sum_abs_errors"] for r in rows)
+        mae = tot_err / total if total > 0 else math.nan
+        nll = total * (1 + math.log(2 * mae)) if not math.isnan(mae) and mae > 0 else math.nan
+        out.append(dict(Holdout_MAE=mae, NLL=nll, mean_iter=float(np.mean([r["iter"] for r in rows])),
+                        pct_converged=100.0 * float(np.mean([r["converged"] for r in rows]))))
+    return out
+
+
+def _sweep_in_the_library(m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order,
+                          precision):
+    """The sweep as ONE library call.  Draws from `rng` exactly what the fold-by-fold loop draws when no fold fails
+    (per set: the fold picks, then per fold its start positions' numbers; then one seed per fold); returns None --
+    with the stream spent, the caller rewinds it -- when a fold has no valid measurements, because such a fold draws
+    nothing in the reference's order."""
+    tiny = core.CodedMatrix(np.array([[0.0, 1.0], [1.0, 0.0]]), np.zeros((2, 2), dtype=np.int32))
+    n = m.values.shape[0]
+    owners, picks, draws, nd, k0, cr, cp = [], [], [], [], [], [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s_idx, ps in enumerate(param_sets):
+            fold_sets = builder.folds(folds, rng)
+            try:    # the parameter checks of R/core.R:202-264, once per set
+                core._validate(tiny, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"], ps["c_repulsion"],
+                               relative_epsilon, 5, 3, None)
+            except ValueError:
+                continue
+            for h in fold_sets:
+                owners.append(s_idx)
+                picks.append(h)
+                draws.append(rng.random((int(ps["N"]), n - 1)))
+                nd.append(int(ps["N"])); k0.append(float(ps["k0"])); cr.append(float(ps["cooling_rate"]))
+                cp.append(float(ps["c_repulsion"]))
+    seeds = [int(rng.integers(0, 2 ** 63 - 1)) for _ in picks]
+    hsum, hcnt, its, conv, ec, secs = _native.cv_sweep(builder.cells(), m.names is not None, preserve_order, nd, k0, cr, cp,
+                                                       picks, draws, seeds, mapping_max_iter, relative_epsilon, 5, 3,
+                                                       precision)
+    if np.any(ec == _native.ERR_BAD_ARGUMENT):
+        return None
+    per_set: List[List[dict]] = [[] for _ in param_sets]
+    for f, owner in enumerate(owners):
+        if ec[f] != _native.OK:
+            continue
+        per_set[owner].append(dict(n_samples=int(hcnt[f]), sum_abs_errors=float(hsum[f]), iter=int(its[f]),
+                                   converged=int(conv[f])))
+    return _pooled(per_set), secs, len(picks)
+
+
 def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]], mapping_max_iter: int,
                      relative_epsilon: float, folds: int = 20, preserve_order: bool = False,
                      rng: Optional[np.random.Generator] = None, precision: str = "f64",
@@ -330,6 +385,10 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     """`likelihood_function` for MANY parameter sets at once: all folds of all sets are relaxed
     in ONE batched launch, and the held-out cells are scored on the device (no est_distances, no
     n x n arrays).  param_sets: dicts with N (ndim), k0, cooling_rate, c_repulsion.
+    path = "sparse" (default) hands the whole sweep to the library in one call (topolow_cv_sweep: folds built on host
+    threads from the picks and the start positions' unit draws, one batch, only the scores come back);
+    "sparse-calls" builds one call object per fold here and relaxes them with optimize_layout_exact_batch -- same
+    draws, same seeds, same numbers (tests/test_gpu_assays.py);
     path = "dense" runs the reference's own sequence per fold instead (masked n x n matrix ->
     prepare_layout_call -> est_distances -> error_calculator_comparison): same folds, same start
     positions, same pooled numbers; kept as the cross-check.
@@ -340,14 +399,20 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     m = core.coded_matrix(dissimilarity_matrix)   # strings are parsed once, not once per fold
     if m is None:
         raise ValueError("dissimilarity_matrix must be a matrix")
-    if path not in ("sparse", "dense"):
-        raise ValueError("path must be 'sparse' or 'dense'")
-    builder = FoldBuilder(m) if path == "sparse" else None
+    if path not in ("sparse", "sparse-calls", "dense"):
+        raise ValueError("path must be 'sparse', 'sparse-calls' or 'dense'")
+    builder = FoldBuilder(m) if path != "dense" else None
     if builder is not None:      # the matrix half of R/core.R:202-264 once; per set only the parameters
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             core._validate(m, 2, 1, 1.0, 0.5, 1.0, 1.0, 1, 1, None)
     state0 = rng.bit_generator.state
+    if path == "sparse":
+        fused = _sweep_in_the_library(m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon,
+                                      preserve_order, precision)
+        if fused is not None:
+            return fused
+        rng.bit_generator.state = state0      # a fold failed: the fold-by-fold order of draws decides (below)
     try:
         calls, owners, inputs, holds = build_fold_calls(
             m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order,
@@ -383,18 +448,7 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
             n_samples, sum_abs = int(oe.size), float(np.abs(oe).sum())
         per_set[owner].append(dict(n_samples=n_samples, sum_abs_errors=sum_abs,
                                    iter=res.iterations, converged=int(res.converged)))
-    out = []
-    for rows in per_set:
-        rows = [r for r in rows if r["n_samples"] > 0]
-        if not rows:
-            out.append(dict(Holdout_MAE=math.nan, NLL=math.nan, mean_iter=math.nan, pct_converged=math.nan))
-            continue
-        total = sum(r["n_samples"] for r in rows)
-        tot_err = sum(r["sum_abs_errors"] for r in rows)
-        mae = tot_err / total if total > 0 else math.nan
-        nll = total * (1 + math.log(2 * mae)) if not math.isnan(mae) and mae > 0 else math.nan
-        out.append(dict(Holdout_MAE=mae, NLL=nll, mean_iter=float(np.mean([r["iter"] for r in rows])),
-                        pct_converged=100.0 * float(np.mean([r["converged"] for r in rows]))))
+    out = _pooled(per_set)
     return out, secs, len(live)
 
 
