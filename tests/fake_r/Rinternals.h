@@ -70,6 +70,7 @@ int Rf_ncols(SEXP x);
 Rboolean Rf_isReal(SEXP x);
 Rboolean Rf_isInteger(SEXP x);
 Rboolean Rf_isString(SEXP x);
+Rboolean Rf_isNewList(SEXP x);
 Rboolean Rf_isMatrix(SEXP x);
 int Rf_asInteger(SEXP x);
 double Rf_asReal(SEXP x);

@@ -131,6 +131,7 @@ int Rf_ncols(SEXP x) { return x->ncol > 0 ? x->ncol : 1; }
 Rboolean Rf_isReal(SEXP x) { return x->type == REALSXP; }
 Rboolean Rf_isInteger(SEXP x) { return x->type == INTSXP; }
 Rboolean Rf_isString(SEXP x) { return x->type == STRSXP; }
+Rboolean Rf_isNewList(SEXP x) { return x->type == VECSXP; }
 Rboolean Rf_isMatrix(SEXP x) { return x->ncol > 0; }
 int Rf_asInteger(SEXP x) { return x->type == REALSXP ? (int)REAL(x)[0] : INTEGER(x)[0]; }
 double Rf_asReal(SEXP x) { return x->type == REALSXP ? REAL(x)[0] : (double)INTEGER(x)[0]; }
@@ -242,7 +243,8 @@ static DL_FUNC find_routine(const char* name, int arity) {
  *   batch  : the same input, sent K times through _topolow_optimize_layout_exact_batch as a list of
  *            argument lists; calls with an odd index pass NULL matrices (the edge list is the matrix);
  *            the first H edges are scored as hold-out pairs.
- *   cvfold : "n m n_picks preserve_order named" then row, col, value, code, picks. */
+ *   cvfold : "n m n_picks preserve_order named" then row, col, value, code, picks.
+ *   cvsweep: the 20-element list of _topolow_cv_sweep (see there), flat. */
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   FILE* f = fopen(argv[1], "r");
@@ -294,6 +296,47 @@ int main(int argc, char** argv) {
       return 0;
     }
     SEXP out = fn(row, col, val, code, Rf_ScalarInteger(n), picks, Rf_ScalarLogical(preserve), Rf_ScalarLogical(named));
+    SEXP names = Rf_getAttrib(out, R_NamesSymbol);
+    printf("{");
+    for (int i = 0; i < Rf_length(out); ++i) {
+      printf("\"%s\": ", CHAR(STRING_ELT(names, i)));
+      print_vec(VECTOR_ELT(out, i));
+      printf(", ");
+    }
+    print_tail();
+    return 0;
+  }
+
+  if (strcmp(mode, "cvsweep") == 0) {
+    /* "n m F preserve named n_iter window freq eps n_picks n_draws" then row, col, value, code (m each), ndim, k0,
+     * cooling_rate, c_repulsion (F each), picks, picks_offset (F + 1), unit_draws, draws_offset (F + 1), seeds (F) */
+    typedef SEXP (*call1)(SEXP);
+    call1 fn = (call1)find_routine("_topolow_cv_sweep", 1);
+    if (!fn) { printf("{\"registration\": \"bad\"}\n"); return 1; }
+    const int n = (int)read_num(f), m = (int)read_num(f), F = (int)read_num(f);
+    const int preserve = (int)read_num(f), named = (int)read_num(f), n_iter = (int)read_num(f);
+    const int window = (int)read_num(f), freq = (int)read_num(f);
+    const double eps = read_num(f);
+    const int np = (int)read_num(f), nd = (int)read_num(f);
+    SEXP a = Rf_allocVector(VECSXP, 20);
+    SET_VECTOR_ELT(a, 0, read_int(f, m, 0)); SET_VECTOR_ELT(a, 1, read_int(f, m, 0));
+    SET_VECTOR_ELT(a, 2, read_real(f, m, 0)); SET_VECTOR_ELT(a, 3, read_int(f, m, 0));
+    SET_VECTOR_ELT(a, 4, Rf_ScalarInteger(n)); SET_VECTOR_ELT(a, 5, Rf_ScalarLogical(named));
+    SET_VECTOR_ELT(a, 6, Rf_ScalarLogical(preserve));
+    SET_VECTOR_ELT(a, 7, read_int(f, F, 0)); SET_VECTOR_ELT(a, 8, read_real(f, F, 0));
+    SET_VECTOR_ELT(a, 9, read_real(f, F, 0)); SET_VECTOR_ELT(a, 10, read_real(f, F, 0));
+    SET_VECTOR_ELT(a, 11, read_real(f, np, 0)); SET_VECTOR_ELT(a, 12, read_real(f, F + 1, 0));
+    SET_VECTOR_ELT(a, 13, read_real(f, nd, 0)); SET_VECTOR_ELT(a, 14, read_real(f, F + 1, 0));
+    SET_VECTOR_ELT(a, 15, read_real(f, F, 0));
+    SET_VECTOR_ELT(a, 16, Rf_ScalarInteger(n_iter)); SET_VECTOR_ELT(a, 17, Rf_ScalarReal(eps));
+    SET_VECTOR_ELT(a, 18, Rf_ScalarInteger(window)); SET_VECTOR_ELT(a, 19, Rf_ScalarInteger(freq));
+    fclose(f);
+    if (setjmp(error_jmp) != 0) {
+      printf("{\"error\": \"%s\", ", error_msg);
+      print_tail();
+      return 0;
+    }
+    SEXP out = fn(a);
     SEXP names = Rf_getAttrib(out, R_NamesSymbol);
     printf("{");
     for (int i = 0; i < Rf_length(out); ++i) {

@@ -179,6 +179,48 @@ def test_batch_entry_equals_the_library_batch(harness, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cv_sweep_entry_equals_the_library_sweep(harness, tmp_path):
+    """`.Call("_topolow_cv_sweep", list(...))`: all folds of a sweep in one call, per-fold scores back -- the same
+    numbers as topolow_cv_sweep driven through ctypes."""
+    rng = np.random.default_rng(8)
+    n = 60
+    pts = rng.normal(size=(n, 3))
+    D = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    D[rng.random((n, n)) < 0.3] = np.nan
+    D = np.where(np.isnan(D) | np.isnan(D.T), np.nan, D)
+    np.fill_diagonal(D, 0.0)
+    m = core.coded_matrix(D)
+    rows, cols = np.nonzero(~np.isnan(m.values.T))
+    rows, cols = cols, rows
+    vals, codes = m.values[rows, cols], m.codes[rows, cols]
+    pos_of = np.full(n * n, -1, np.int64)
+    pos_of[rows + cols * n] = np.arange(rows.size)
+    cells = _native.CellList(n, rows, cols, vals, codes, pos_of)
+    lin = (rows + cols * n)[rows != cols]
+    F = 6
+    ndim = [2, 3, 2, 4, 3, 2]
+    picks = [rng.choice(lin, size=40, replace=False) for _ in range(F)]
+    draws = [rng.random((d, n - 1)) for d in ndim]
+    k0, cool, crep = [3.0 + f for f in range(F)], [0.02] * F, [0.01] * F
+    seeds = [11 + f for f in range(F)]
+    want = _native.cv_sweep(cells, False, False, ndim, k0, cool, crep, picks, draws, seeds, 80, 1e-4, 5, 3, "f64")
+    p_off = np.concatenate([[0], np.cumsum([p.size for p in picks])])
+    d_off = np.concatenate([[0], np.cumsum([u.size for u in draws])])
+    lines = ["mode cvsweep", f"{n} {rows.size} {F} 0 0 80 5 3 1e-4 {int(p_off[-1])} {int(d_off[-1])}", _fmt(rows), _fmt(cols),
+             _fmt(vals), _fmt(codes), _fmt(ndim), _fmt(k0), _fmt(cool), _fmt(crep), _fmt(np.concatenate(picks)), _fmt(p_off),
+             " ".join(repr(float(x)) for u in draws for x in u.ravel()), _fmt(d_off), _fmt(seeds)]
+    path = tmp_path / "sweep.txt"
+    path.write_text("\n".join(lines) + "\n")
+    res = subprocess.run([harness, str(path)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    got = json.loads(res.stdout)
+    hsum, hcnt, its, conv, ec, _secs = want
+    assert got["holdout_sum_abs"] == hsum.tolist() and got["holdout_count"] == hcnt.tolist()
+    assert got["iterations"] == its.tolist() and got["converged"] == conv.tolist() and got["error_code"] == ec.tolist()
+    assert got["protect_depth"] == 0 and all(c > 0 for c in hcnt)
+
+
+@pytest.mark.gpu
 def test_interrupt_is_reraised_after_cleanup(harness, tmp_path):
     call = core.prepare_layout_call(quickstart_matrix(), 2, 400, 5.0, 1e-4, 0.7, 1e-12, 1000,
                                     None, False, 3, False, np.random.default_rng(4))

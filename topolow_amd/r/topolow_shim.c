@@ -10,6 +10,7 @@
  *                                           of likelihood_function (R/adaptive_sampling.R:2604-2693)
  *     _topolow_cv_fold                      one fold's payload from the list of non-NA cells
  *                                           (R/adaptive_sampling.R:2608-2616 + R/core.R:269-436)
+ *     _topolow_cv_sweep                     all folds of all parameter sets in one call: per-fold out-of-sample scores
  *     _topolow_est_distances                as.matrix(dist(positions))  (R/core.R:474)
  *     _topolow_est_distances_cols           a block of its columns, for n x n results too large to hold
  *
@@ -354,6 +355,84 @@ SEXP _topolow_cv_fold(SEXP rowSEXP, SEXP colSEXP, SEXP valueSEXP, SEXP codeSEXP,
   return out;
 }
 
+/* A whole cross-validation sweep (topolow_cv_sweep): ONE argument, a list of 20 in this order --
+ *   row, col (integer, 0-based), value (double), code (integer): the non-NA cells of the matrix, column-major order;
+ *   n; named (logical); preserve_order (logical);
+ *   ndim (integer), k0, cooling_rate, c_repulsion (double): one entry per fold;
+ *   picks (held-out cells, linear column-major indices, all folds one after another), picks_offset (F + 1);
+ *   unit_draws (per fold ndim x (n - 1) runif(0, 1) numbers, row-major, one after another), draws_offset (F + 1);
+ *   seeds (one per fold); n_iter; relative_epsilon; convergence_counter; convergence_check_freq.
+ * Returns list(holdout_sum_abs, holdout_count, iterations, converged, error_code, device_seconds): what
+ * likelihood_function pools per parameter set (R/adaptive_sampling.R:2660-2720). */
+static int64_t* as_i64(SEXP v, int64_t* len) {
+  const int64_t m = (int64_t)XLENGTH(v);
+  int64_t* out = (int64_t*)R_alloc(m > 0 ? (size_t)m : 1, sizeof(int64_t));
+  for (int64_t q = 0; q < m; ++q) out[q] = Rf_isInteger(v) ? (int64_t)INTEGER(v)[q] : (int64_t)REAL(v)[q];
+  if (len) *len = m;
+  return out;
+}
+
+SEXP _topolow_cv_sweep(SEXP a) {
+  if (!Rf_isNewList(a) || Rf_length(a) != 20) Rf_error("cv_sweep: one list of 20 elements expected");
+  SEXP row = VECTOR_ELT(a, 0), col = VECTOR_ELT(a, 1), value = VECTOR_ELT(a, 2), code = VECTOR_ELT(a, 3);
+  if (!Rf_isInteger(row) || !Rf_isInteger(col) || !Rf_isReal(value) || !Rf_isInteger(code))
+    Rf_error("row, col, code must be integer and value double");
+  const int n = Rf_asInteger(VECTOR_ELT(a, 4));
+  const int64_t m = (int64_t)XLENGTH(row);
+  if (n < 1 || XLENGTH(col) != m || XLENGTH(value) != m || XLENGTH(code) != m)
+    Rf_error("cell columns must have one length and n must be positive");
+  SEXP ndim = VECTOR_ELT(a, 7), k0 = VECTOR_ELT(a, 8), cool = VECTOR_ELT(a, 9), crep = VECTOR_ELT(a, 10);
+  const int F = Rf_length(ndim);
+  if (!Rf_isInteger(ndim) || !Rf_isReal(k0) || !Rf_isReal(cool) || !Rf_isReal(crep) || Rf_length(k0) != F ||
+      Rf_length(cool) != F || Rf_length(crep) != F || !Rf_isReal(VECTOR_ELT(a, 13)))
+    Rf_error("per-fold parameters: integer ndim, double k0 / cooling_rate / c_repulsion / unit_draws of one length");
+  int64_t np = 0, npo = 0, ndo = 0, ns = 0;
+  int64_t* picks = as_i64(VECTOR_ELT(a, 11), &np);
+  int64_t* p_off = as_i64(VECTOR_ELT(a, 12), &npo);
+  int64_t* d_off = as_i64(VECTOR_ELT(a, 14), &ndo);
+  int64_t* seeds_i = as_i64(VECTOR_ELT(a, 15), &ns);
+  if (npo != F + 1 || ndo != F + 1 || ns != F || p_off[F] != np || d_off[F] != (int64_t)XLENGTH(VECTOR_ELT(a, 13)))
+    Rf_error("offsets must have one entry per fold plus one and end at the lengths of picks / unit_draws");
+  uint64_t* seeds = (uint64_t*)R_alloc(F > 0 ? (size_t)F : 1, sizeof(uint64_t));
+  for (int f = 0; f < F; ++f) seeds[f] = (uint64_t)seeds_i[f];
+  int64_t* pos_of = (int64_t*)R_alloc((size_t)n * n, sizeof(int64_t));
+  int64_t* by_row = (int64_t*)R_alloc(m > 0 ? (size_t)m : 1, sizeof(int64_t));
+  int64_t* row_ptr = (int64_t*)R_alloc((size_t)n + 1, sizeof(int64_t));
+  if (topolow_cell_list_index(n, m, INTEGER(row), INTEGER(col), pos_of, by_row, row_ptr) != TOPOLOW_OK)
+    Rf_error("cell list: row / col out of range");
+  topolow_cell_list cells;
+  memset(&cells, 0, sizeof cells);
+  cells.n = n; cells.n_cells = m;
+  cells.row = INTEGER(row); cells.col = INTEGER(col); cells.value = REAL(value); cells.code = INTEGER(code);
+  cells.pos_of = pos_of; cells.by_row = by_row; cells.row_ptr = row_ptr;
+  static const char* const names[] = {"holdout_sum_abs", "holdout_count", "iterations", "converged", "error_code",
+                                      "device_seconds"};
+  SEXP out = PROTECT(named_list(6, names));
+  SEXP hs = PROTECT(Rf_allocVector(REALSXP, F)), hc = PROTECT(Rf_allocVector(REALSXP, F));
+  SEXP it = PROTECT(Rf_allocVector(INTSXP, F)), cv = PROTECT(Rf_allocVector(INTSXP, F)), ec = PROTECT(Rf_allocVector(INTSXP, F));
+  int64_t* hcount = (int64_t*)R_alloc(F > 0 ? (size_t)F : 1, sizeof(int64_t));
+  double secs = 0.0;
+  char err[512];
+  err[0] = 0;
+  const int precision = opt_choice("topolow.precision", "f32", TOPOLOW_PRECISION_F32, "f64", TOPOLOW_PRECISION_F64,
+                                   TOPOLOW_PRECISION_F64);
+  const int rc = topolow_cv_sweep(&cells, Rf_asLogical(VECTOR_ELT(a, 5)), Rf_asLogical(VECTOR_ELT(a, 6)), F, INTEGER(ndim),
+                                  REAL(k0), REAL(cool), REAL(crep), picks, p_off, REAL(VECTOR_ELT(a, 13)), d_off, seeds,
+                                  Rf_asInteger(VECTOR_ELT(a, 16)), Rf_asReal(VECTOR_ELT(a, 17)),
+                                  Rf_asInteger(VECTOR_ELT(a, 18)), Rf_asInteger(VECTOR_ELT(a, 19)), precision,
+                                  opt_int("topolow.device", -1), REAL(hs), hcount, INTEGER(it), INTEGER(cv), INTEGER(ec),
+                                  &secs, err, sizeof err);
+  if (rc != TOPOLOW_OK) {
+    UNPROTECT(6);
+    Rf_error("%s", err[0] ? err : "topolow_cv_sweep failed");
+  }
+  for (int f = 0; f < F; ++f) REAL(hc)[f] = (double)hcount[f];
+  SET_VECTOR_ELT(out, 0, hs); SET_VECTOR_ELT(out, 1, hc); SET_VECTOR_ELT(out, 2, it); SET_VECTOR_ELT(out, 3, cv);
+  SET_VECTOR_ELT(out, 4, ec); SET_VECTOR_ELT(out, 5, Rf_ScalarReal(secs));
+  UNPROTECT(6);
+  return out;
+}
+
 /* Optional: as.matrix(dist(positions)) on the GPU (reference R/core.R:474). */
 SEXP _topolow_est_distances(SEXP positionsSEXP) {
   if (!Rf_isReal(positionsSEXP) || !Rf_isMatrix(positionsSEXP))
@@ -392,6 +471,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_topolow_optimize_layout_exact_cpp", (DL_FUNC)&_topolow_optimize_layout_exact_cpp, 16},
     {"_topolow_optimize_layout_exact_batch", (DL_FUNC)&_topolow_optimize_layout_exact_batch, 1},
     {"_topolow_cv_fold", (DL_FUNC)&_topolow_cv_fold, 8},
+    {"_topolow_cv_sweep", (DL_FUNC)&_topolow_cv_sweep, 1},
     {"_topolow_est_distances", (DL_FUNC)&_topolow_est_distances, 1},
     {"_topolow_est_distances_cols", (DL_FUNC)&_topolow_est_distances_cols, 3},
     {NULL, NULL, 0}};
