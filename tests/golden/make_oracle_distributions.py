@@ -47,13 +47,18 @@ def _one(args):
     from oracle import topolow_oracle as orc
     from tests.conftest import layout_call_args
     from tests import parity_problems
-    call, truth = parity_problems.build(name)
+    spec = parity_problems.PROBLEMS[name]
+    call, truth = spec["fn"](seed) if spec.get("vary_init") else parity_problems.build(name)
     t0 = time.time()
     r = orc.optimize_layout_exact(*layout_call_args(call), seed=seed)
     post = None
     if truth is not None:
         _, post = oracle.post_metrics(r.positions, truth)
-    return dict(seed=seed, final_mae=r.final_mae, iterations=int(r.iterations), iters_run=int(r.iters_run),
+    edges = None
+    if parity_problems.PROBLEMS[name].get("edges"):     # distances of the measured pairs (rotation-free)
+        ei, ej = np.asarray(call.edge_i), np.asarray(call.edge_j)
+        edges = np.linalg.norm(r.positions[ei] - r.positions[ej], axis=1).tolist()
+    return dict(seed=seed, edges=edges, final_mae=r.final_mae, iterations=int(r.iterations), iters_run=int(r.iters_run),
                 converged=bool(r.converged), final_k=r.final_k, post_mae=post, seconds=time.time() - t0,
                 head=head_dist(r.positions).tolist())
 
@@ -69,6 +74,7 @@ def main():
         t0 = time.time()
         with ProcessPoolExecutor(a.jobs) as ex:
             recs = list(ex.map(_one, [(name, 1000 + s) for s in range(a.seeds)]))
+        edges = [r.pop("edges") for r in recs]
         heads = np.array([r.pop("head") for r in recs])
         mean_head = heads.mean(0)
         gaps = [float(np.mean(np.abs(h - mean_head) / mean_head)) for h in heads]
@@ -80,6 +86,11 @@ def main():
                    sd_iterations=float(np.std([r["iterations"] for r in recs], ddof=1)),
                    runs=recs, head_points=HEAD, head_dist_mean=[round(float(v), 6) for v in mean_head],
                    head_gap=gaps)
+        if edges[0] is not None:
+            ed = np.array(edges)
+            em = ed.mean(0)
+            out["edge_dist_mean"] = [round(float(v), 6) for v in em]
+            out["edge_gap"] = [float(np.mean(np.abs(e - em)) / em.mean()) for e in ed]
         path = os.path.join(HERE, f"oracle_dist_{name}.json")
         with open(path, "w") as fh:
             json.dump(out, fh)

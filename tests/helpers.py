@@ -41,3 +41,32 @@ def quickstart_matrix():
     D = numpy_pdist(pts)
     D[3, 4] = D[4, 3] = np.nan
     return core.RMatrix(D, ["S1", "S2", "S3", "V1", "V2"])
+
+
+def oracle_cv(matrix, params, folds, rng, mapping_max_iter=500, relative_epsilon=1e-4, convergence_counter=5,
+              seed0=0):
+    """The reference's k-fold evaluator (R/adaptive_sampling.R:2552-2726: folds of floor(#non-NA / 2 folds) cells,
+    masked symmetrically, one embedding per fold, out-of-sample errors of the numeric held-out cells) with the CPU
+    oracle standing in for the `.Call` -- the CPU twin of topolow_amd.cv.likelihood_sweep(path="dense").
+    Returns the pooled dict of likelihood_function plus `fold_mae` (mean |error| per fold: what the reference's
+    notebook aggregates into fold_stats.csv, inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:2024-2028)."""
+    from tests.conftest import layout_call_args
+    from topolow_amd import cv
+    m = core.coded_matrix(matrix)
+    n = m.values.shape[0]
+    rows = []
+    for f, h in enumerate(cv.make_folds(m.values, folds, rng)):
+        masked = m.masked(h % n, h // n)
+        call = core.prepare_layout_call(masked, int(params["N"]), mapping_max_iter, params["k0"],
+                                        params["cooling_rate"], params["c_repulsion"], relative_epsilon,
+                                        convergence_counter, None, False, 3, False, rng)
+        r = orc.optimize_layout_exact(*layout_call_args(call), seed=seed0 + f)
+        err = cv.error_calculator_comparison(numpy_pdist(r.positions), m, masked, pred_names=call.names,
+                                             true_names=m.names)
+        oe = err["OutSampleError"]
+        oe = oe[~np.isnan(oe)]
+        rows.append(dict(n_samples=int(oe.size), sum_abs_errors=float(np.abs(oe).sum()), iter=int(r.iterations),
+                         converged=int(r.converged)))
+    out = cv._pooled([rows])[0]
+    out["fold_mae"] = [r["sum_abs_errors"] / r["n_samples"] for r in rows if r["n_samples"] > 0]
+    return out

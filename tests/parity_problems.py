@@ -76,6 +76,71 @@ def h3n2_call(ndim):
                                     H3N2["c_repulsion"], 1e-4, 5, None, False, 3, False, np.random.default_rng(7))
 
 
+def hiv_matrix():
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "hiv_distances.csv"))))
+    return antigenic.titers_list_to_matrix(rows, "Virus", "virusYear", "Antibody", None, "distance", sort=True)
+
+
+# ---- the results the reference itself ships (tests/golden/ref_results/, copied by make_reference_results.py) ----
+REF_RESULTS = os.path.join(GOLD, "ref_results")
+HIV_LISTED = dict(N=2, k0=3.550036, cooling_rate=0.04130713, c_repulsion=0.0007038619)   # ...h3n2-hiv-denv.Rmd:319-323
+H3N2_LISTED = dict(N=4, **H3N2)
+
+
+def ref_coordinates(ds):
+    """(names, positions) of the embedding the reference ships for data set `ds` ("H3N2" | "HIV")."""
+    rows = list(csv.reader(open(os.path.join(REF_RESULTS, f"topolow_{ds}_coords.csv"))))
+    return [r[0] for r in rows[1:]], np.array([[float(x) for x in r[1:]] for r in rows[1:]])
+
+
+def ref_chain_optimum(ds):
+    with open(os.path.join(REF_RESULTS, "chain_optimum.json")) as fh:
+        return json.load(fh)[ds]
+
+
+def ref_chain_sample(ds):
+    """Rows of the reference's adaptive-sampling chains: dicts N, k0, cooling_rate, c_repulsion, Holdout_MAE, NLL."""
+    out = []
+    for r in csv.DictReader(open(os.path.join(REF_RESULTS, f"chain_sample_{ds}.csv"))):
+        out.append(dict(N=int(round(np.exp(float(r["log_N"])))), k0=float(np.exp(float(r["log_k0"]))),
+                        cooling_rate=float(np.exp(float(r["log_cooling_rate"]))),
+                        c_repulsion=float(np.exp(float(r["log_c_repulsion"]))),
+                        Holdout_MAE=float(r["Holdout_MAE"]), NLL=float(r["NLL"])))
+    return out
+
+
+def ref_fold_stats(ds, algorithm="Topolow"):
+    rows = csv.DictReader(open(os.path.join(REF_RESULTS, "fold_stats.csv")))
+    return np.array([float(r["OutSampleError"]) for r in rows if r["Dataset"] == ds and r["Algorithm"] == algorithm])
+
+
+@functools.lru_cache(maxsize=4)
+def ref_matrix(ds):
+    """The panel of data set `ds` with its rows in the order of the reference's coordinate file (H3N2: that IS the
+    order titers_list_to_matrix builds; HIV: the file lists the viruses in another order), so that a run with
+    preserve_order relaxes exactly the problem whose solution the reference holds."""
+    m = core.coded_matrix(h3n2_matrix() if ds == "H3N2" else hiv_matrix())
+    names, _ = ref_coordinates(ds)
+    at = {nm: q for q, nm in enumerate(m.names)}
+    perm = np.array([at[nm] for nm in names])
+    return m if np.array_equal(perm, np.arange(len(names))) else m.reordered(perm)
+
+
+def refrun_call(ds, params, init_seed=7, init=None, n_iter=500, k0=None):
+    """The call that wrote the reference's coordinate file (methods-comparison-h3n2-hiv-denv.Rmd:902-912):
+    mapping_max_iter 500, relative_epsilon 1e-10, convergence_counter 3, default check frequency."""
+    return core.prepare_layout_call(ref_matrix(ds), params["N"], n_iter, params["k0"] if k0 is None else k0,
+                                    params["cooling_rate"], params["c_repulsion"], 1e-10, 3, init, False, 3, True,
+                                    np.random.default_rng(init_seed))
+
+
+def _refrun(ds, which, init_seed=7):
+    params = ref_chain_optimum(ds) if which == "chain" else dict(HIV_LISTED if ds == "HIV" else H3N2_LISTED)
+    if ds == "H3N2":
+        params["N"] = 5          # the width of the shipped coordinate file
+    return refrun_call(ds, params, init_seed), None
+
+
 def _syn1500():
     call, prob = random_problem(1500, 5, 0.7, seed=777, n_iter=1000, k0=14.76, cool=0.0364, c_rep=0.00294)
     return call, prob.dissimilarity
@@ -117,6 +182,19 @@ PROBLEMS = {
     "h3n2_ndim4": dict(fn=lambda: (h3n2_call(4), None), doc="Smith-2004 H3N2 panel (tests/golden/"
                        "h3n2_distances.csv), ndim 4, published parameters, start positions default_rng(7)"),
     "h3n2_ndim5": dict(fn=lambda: (h3n2_call(5), None), doc="the same, ndim 5 (BASELINE config 2)"),
+    # (vary_init: the oracle distribution draws new start positions per seed -- fn(init_seed) -- as the reference's
+    #  runs do; the other problems fix the start and vary the pair order only)
+    # the runs whose results the reference ships (tests/golden/ref_results/): same panel in the coordinate file's row
+    # order, preserve_order, 500 iterations, eps 1e-10, window 3; "chain" = the parameters the notebook's rule picks
+    # from the shipped chains (chain_optimum.json), "listed" = the ones its text prints (...Rmd:312-323)
+    "h3n2_refrun_chain": dict(fn=functools.partial(_refrun, "H3N2", "chain"), edges=True, vary_init=True,
+                              doc="refrun_call('H3N2', chain optimum): ndim 5, k0 4.84, cooling 0.0161, c_rep 0.0118"),
+    "h3n2_refrun_listed": dict(fn=functools.partial(_refrun, "H3N2", "listed"), edges=True, vary_init=True,
+                               doc="refrun_call('H3N2', listed parameters at ndim 5)"),
+    "hiv_refrun_chain": dict(fn=functools.partial(_refrun, "HIV", "chain"), edges=True, vary_init=True,
+                             doc="refrun_call('HIV', chain optimum): ndim 2, k0 8.20, cooling 0.0310, c_rep 0.0194"),
+    "hiv_refrun_listed": dict(fn=functools.partial(_refrun, "HIV", "listed"), edges=True, vary_init=True,
+                              doc="refrun_call('HIV', listed parameters): ndim 2, k0 3.55, cooling 0.0413, c_rep 0.000704"),
 }
 
 

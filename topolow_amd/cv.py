@@ -269,7 +269,7 @@ def _fold_workers() -> int:
 
 
 def build_fold_calls(m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order,
-                     parallel: bool):
+                     parallel: bool, convergence_counter: int = 5):
     """All folds of all parameter sets: (calls, owners, masked inputs, holdouts).  One sequential pass over the
     random stream (fold picks, then each fold's start-position draws, in the order the reference's loop consumes
     them); parallel = True: the list work of the folds (topolow_cv_fold, which releases the interpreter lock) then
@@ -296,13 +296,13 @@ def build_fold_calls(m, builder, param_sets, folds, rng, mapping_max_iter, relat
                         masked = m.masked(h % n_pts, h // n_pts)
                         call = core.prepare_layout_call(masked, int(ps["N"]), mapping_max_iter, ps["k0"],
                                                         ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
-                                                        5, None, False, 3, preserve_order, rng)
+                                                        convergence_counter, None, False, 3, preserve_order, rng)
                     elif set_ok and parallel:
                         jobs.append((len(calls), h, ps, rng.random((int(ps["N"]), n_pts - 1))))
                     elif set_ok:
                         call, hold = builder.fold(h, int(ps["N"]), mapping_max_iter, ps["k0"],
                                                   ps["cooling_rate"], ps["c_repulsion"], relative_epsilon,
-                                                  5, 3, preserve_order, rng)
+                                                  convergence_counter, 3, preserve_order, rng)
                 except ValueError:
                     call = None  # the reference's tryCatch turns a failed fold into an NA row
                 calls.append(call)
@@ -315,8 +315,8 @@ def build_fold_calls(m, builder, param_sets, folds, rng, mapping_max_iter, relat
             def one(job):
                 q, h, ps, u = job
                 return q, builder.fold_from_draw(h, int(ps["N"]), mapping_max_iter, ps["k0"], ps["cooling_rate"],
-                                                 ps["c_repulsion"], relative_epsilon, 5, 3, preserve_order,
-                                                 unit_draw=u)
+                                                 ps["c_repulsion"], relative_epsilon, convergence_counter, 3,
+                                                 preserve_order, unit_draw=u)
             with ThreadPoolExecutor(max_workers=_fold_workers()) as pool:
                 for q, (call, hold) in pool.map(one, jobs):
                     calls[q], holds[q] = call, hold
@@ -328,19 +328,20 @@ def _pooled(per_set):
     for rows in per_set:
         rows = [r for r in rows if r["n_samples"] > 0]
         if not rows:
-            out.append(dict(Holdout_MAE=math.nan, NLL=math.nan, mean_iter=math.nan, pct_converged=math.nan))
+            out.append(dict(Holdout_MAE=math.nan, NLL=math.nan, mean_iter=math.nan, pct_converged=math.nan, fold_mae=[]))
             continue
         total = sum(r["n_samples"] for r in rows)
         tot_err = sum(r["sum_abs_errors"] for r in rows)
         mae = tot_err / total if total > 0 else math.nan
         nll = total * (1 + math.log(2 * mae)) if not math.isnan(mae) and mae > 0 else math.nan
         out.append(dict(Holdout_MAE=mae, NLL=nll, mean_iter=float(np.mean([r["iter"] for r in rows])),
-                        pct_converged=100.0 * float(np.mean([r["converged"] for r in rows]))))
+                        pct_converged=100.0 * float(np.mean([r["converged"] for r in rows])),
+                        fold_mae=[r["sum_abs_errors"] / r["n_samples"] for r in rows]))
     return out
 
 
 def _sweep_in_the_library(m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order,
-                          precision):
+                          precision, convergence_counter: int = 5):
     """The sweep as ONE library call.  Draws from `rng` exactly what the fold-by-fold loop draws when no fold fails
     (per set: the fold picks, then per fold its start positions' numbers; then one seed per fold); returns None --
     with the stream spent, the caller rewinds it -- when a fold has no valid measurements, because such a fold draws
@@ -365,8 +366,8 @@ def _sweep_in_the_library(m, builder, param_sets, folds, rng, mapping_max_iter, 
                 cp.append(float(ps["c_repulsion"]))
     seeds = [int(rng.integers(0, 2 ** 63 - 1)) for _ in picks]
     hsum, hcnt, its, conv, ec, secs = _native.cv_sweep(builder.cells(), m.names is not None, preserve_order, nd, k0, cr, cp,
-                                                       picks, draws, seeds, mapping_max_iter, relative_epsilon, 5, 3,
-                                                       precision)
+                                                       picks, draws, seeds, mapping_max_iter, relative_epsilon,
+                                                       convergence_counter, 3, precision)
     if np.any(ec == _native.ERR_BAD_ARGUMENT):
         return None
     per_set: List[List[dict]] = [[] for _ in param_sets]
@@ -381,7 +382,7 @@ def _sweep_in_the_library(m, builder, param_sets, folds, rng, mapping_max_iter, 
 def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]], mapping_max_iter: int,
                      relative_epsilon: float, folds: int = 20, preserve_order: bool = False,
                      rng: Optional[np.random.Generator] = None, precision: str = "f64",
-                     path: str = "sparse"):
+                     path: str = "sparse", convergence_counter: int = 5):
     """`likelihood_function` for MANY parameter sets at once: all folds of all sets are relaxed
     in ONE batched launch, and the held-out cells are scored on the device (no est_distances, no
     n x n arrays).  param_sets: dicts with N (ndim), k0, cooling_rate, c_repulsion.
@@ -392,6 +393,9 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     path = "dense" runs the reference's own sequence per fold instead (masked n x n matrix ->
     prepare_layout_call -> est_distances -> error_calculator_comparison): same folds, same start
     positions, same pooled numbers; kept as the cross-check.
+    convergence_counter: 5 is what likelihood_function passes (R/adaptive_sampling.R:2620-2631); the reference's
+    notebooks run the same folds with 3 (inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:1894-1902).
+    Each result dict carries likelihood_function's four fields plus `fold_mae` (mean |error| per fold).
     Returns (list of result dicts, device_seconds, embeddings)."""
     rng = rng if rng is not None else _native.host_rng()
     if not hasattr(rng, "choice"):   # R-stream generator: fold sampling uses a NumPy stream seeded from it
@@ -409,18 +413,19 @@ def likelihood_sweep(dissimilarity_matrix, param_sets: Sequence[Dict[str, float]
     state0 = rng.bit_generator.state
     if path == "sparse":
         fused = _sweep_in_the_library(m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon,
-                                      preserve_order, precision)
+                                      preserve_order, precision, convergence_counter)
         if fused is not None:
             return fused
         rng.bit_generator.state = state0      # a fold failed: the fold-by-fold order of draws decides (below)
     try:
         calls, owners, inputs, holds = build_fold_calls(
             m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order,
-            parallel=builder is not None and len(param_sets) * folds >= 16)
+            parallel=builder is not None and len(param_sets) * folds >= 16, convergence_counter=convergence_counter)
     except Exception:
         rng.bit_generator.state = state0
         calls, owners, inputs, holds = build_fold_calls(
-            m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order, parallel=False)
+            m, builder, param_sets, folds, rng, mapping_max_iter, relative_epsilon, preserve_order, parallel=False,
+            convergence_counter=convergence_counter)
     live = [q for q, c in enumerate(calls) if c is not None]
     seeds = [int(rng.integers(0, 2 ** 63 - 1)) for _ in live]
     results, secs = ([], 0.0)
@@ -498,4 +503,4 @@ def likelihood_function(dissimilarity_matrix, mapping_max_iter, relative_epsilon
     res, _, _ = likelihood_sweep(dissimilarity_matrix,
                                  [dict(N=N, k0=k0, cooling_rate=cooling_rate, c_repulsion=c_repulsion)],
                                  mapping_max_iter, relative_epsilon, folds, preserve_order)
-    return res[0]
+    return {k: v for k, v in res[0].items() if k != "fold_mae"}      # the reference's four fields
