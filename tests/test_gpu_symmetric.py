@@ -108,3 +108,151 @@ def test_single_block_engine_run_takes_the_symmetric_sweep_too():
     assert np.array_equal(a.positions, b.positions)
     assert a.iterations == b.iterations and b.final_mae == pytest.approx(a.final_mae, rel=1e-12)
     assert np.allclose(ta[:, 1], tb[:, 1], rtol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------
+# the symmetric sweep against the CPU model of a one-stage iteration and against the oracle's edge error --
+# directly, not through the row-owner kernel (size gate lowered with TOPOLOW_SYMMETRIC_MIN_N)
+# ----------------------------------------------------------------------------------------
+import dataclasses
+
+from oracle import topolow_oracle as orc
+from tests.models import slab_model
+from tests.test_gpu_parity import _decode_rounded
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _with_thresholds(call, frac, seed=3):
+    if frac > 0:
+        rng = np.random.default_rng(seed)
+        code = rng.choice([0, 1, -1], size=call.edge_thresh.shape[0], p=[1 - frac, frac / 2, frac / 2])
+        et = code.astype(call.edge_thresh.dtype)
+        T = call.threshold_matrix.copy()
+        T[call.edge_i, call.edge_j] = et
+        T[call.edge_j, call.edge_i] = et
+        call = dataclasses.replace(call, edge_thresh=et, threshold_matrix=T)
+    return call
+
+
+def _symmetric_session(call, n, dim, iters, k0, cooling, c_rep, check_freq, profile, relabel=0):
+    """A whole-matrix fp32 session forced onto the symmetric sweep: ONE stage per iteration, no early stop."""
+    with _Env(TOPOLOW_SYMMETRIC="1", TOPOLOW_SYMMETRIC_MIN_N="0"):
+        s = _native.Session(n, dim, precision="f32")
+    if relabel:
+        s.set_relabel(relabel)
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    s.set_positions(call.initial_positions)
+    s.set_profiling(profile)
+    s.begin(iters, k0, cooling, c_rep, 1e-12, 10 ** 9, check_freq, 5, 1)
+    s.run()
+    s.sync()
+    pos = s.get_positions()
+    trace = s.check_trace()
+    counts = s.profile_symmetric() if profile else None
+    s.close()
+    return pos, trace, counts
+
+
+def _model_iterations(call_r, iters, k0, cooling, c_rep):
+    """Positions after 1..iters one-stage iterations of the CPU model (f64; reference update src/optimization.cpp:
+    203-281 applied to every ordered pair from the positions the previous iteration left)."""
+    n = call_r.initial_positions.shape[0]
+    out, pos, k = [], call_r.initial_positions, k0
+    for _ in range(iters):
+        pos = slab_model.stage(pos, call_r.dissimilarity_matrix, call_r.threshold_matrix, call_r.degrees, [[0, n]], k,
+                               c_rep, "f64")
+        out.append(pos)
+        k *= 1.0 - cooling
+    return out
+
+
+@pytest.mark.parametrize("n", [33, 65, 1000, 7205])
+@pytest.mark.parametrize("dim,thr", [(2, 0.0), (3, 0.15), (4, 0.0), (5, 0.0), (5, 0.15), (6, 0.0)])
+def test_symmetric_sweep_against_the_model_and_the_oracle(n, dim, thr):
+    """n: 33 and 65 leave 31 phantom rows/columns in the last tile (and fewer tiles than waves), 1000 and 7205 have
+    n % 32 = 8 / 5; every diagonal tile meets its pairs twice at half weight.  One and seven iterations at one stage:
+    positions against slab_model.stage in f64 (bands of test_slab_f32_close_to_model: mean 5e-5, max 5e-3 of the
+    displacement scale); the checks at iterations 3 and 6 ride on the sweeps of iterations 4 and 7 (ERR instance):
+    their (sum / count) against orc.edge_error of the positions those sweeps read (2e-5, fp32)."""
+    k0, cooling, c_rep = 1.5, 0.01, 0.01
+    call, _ = pp.random_problem(n, dim, 0.7 if n > 100 else 0.3, seed=90 + n % 50 + dim, n_iter=7, k0=k0)
+    call = _with_thresholds(call, thr)
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    want = _model_iterations(call_r, 7, k0, cooling, c_rep)
+    scale = np.abs(want[-1] - call.initial_positions).max()
+    for iters in (1, 7):
+        got, trace, counts = _symmetric_session(call, n, dim, iters, k0, cooling, c_rep, 3, profile=True)
+        assert counts[1] + counts[3] == iters, counts            # every iteration ran as a symmetric sweep + apply
+        err = np.abs(got - want[iters - 1])
+        assert err.mean() <= 5e-5 * scale and err.max() <= 5e-3 * scale, (err.mean() / scale, err.max() / scale)
+        if iters == 7:
+            assert counts[3] == 2                                # ... two of them also reduced a check's MAE
+            assert [int(t) for t in trace[:, 0]] == [3, 6, 7]
+            for row in trace:
+                s, c = orc.edge_error(want[int(row[0]) - 1], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+                assert row[1] == pytest.approx(s / c, rel=2e-5), (row, s / c)
+        # the unprofiled run (checks beside the next iteration on the second stream) gives the same bits
+        again, trace2, _ = _symmetric_session(call, n, dim, iters, k0, cooling, c_rep, 3, profile=False)
+        assert np.array_equal(again, got) and np.array_equal(trace2, trace)
+
+
+def test_symmetric_sweep_with_random_labels_against_the_model():
+    """The production entry stores the points in a random order (topolow_session_set_relabel): the sweep then tiles
+    the relabelled matrix; host-facing positions stay in the caller's labels."""
+    n, dim, k0 = 1000, 5, 1.5
+    call, _ = pp.random_problem(n, dim, 0.7, seed=5, n_iter=3, k0=k0)
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    want = _model_iterations(call_r, 3, k0, 0.01, 0.01)
+    got, _, counts = _symmetric_session(call, n, dim, 3, k0, 0.01, 0.01, 3, profile=True, relabel=77)
+    assert counts[1] + counts[3] == 3
+    scale = np.abs(want[-1] - call.initial_positions).max()
+    err = np.abs(got - want[-1])
+    assert err.mean() <= 5e-5 * scale and err.max() <= 5e-3 * scale
+
+
+def test_symmetric_sweep_at_config3_size_against_the_model():
+    """BASELINE config 3 (N = 10 000, ndim 5, 70 % missing): ONE symmetric sweep from the reference's start positions
+    against the model's one-stage iteration over all 10^8 ordered pairs, and the fused check of that sweep's input
+    against the oracle's edge error (1.5 x 10^7 edges)."""
+    from topolow_amd import core, synthetic
+    n, dim = 10000, 5
+    prob = synthetic.make_problem(n, latent_dim=dim, missing=0.7, seed=12345)
+    init = synthetic.initial_positions(prob.dissimilarity, dim, 12345)
+    call = core.prepare_layout_call(prob.dissimilarity, dim, 2, 2.0, 0.01, 0.01, 1e-4, 5, init, False, 1, True)
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    want = _model_iterations(call_r, 2, 2.0, 0.01, 0.01)
+    with _Env(TOPOLOW_SYMMETRIC="1"):                      # default size gate: 10 000 >= 7 168
+        s = _native.Session(n, dim, precision="f32")
+    s.set_relabel(3)
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    s.set_positions(call.initial_positions)
+    s.set_profiling(True)
+    s.begin(2, 2.0, 0.01, 0.01, 1e-12, 10 ** 9, 1, 5, 1)   # a check after every iteration: iteration 2's sweep is the ERR instance
+    s.run()
+    s.sync()
+    got, trace, counts = s.get_positions(), s.check_trace(), s.profile_symmetric()
+    s.close()
+    assert counts[1] == 1 and counts[3] == 1
+    scale = np.abs(want[-1] - call.initial_positions).max()
+    err = np.abs(got - want[-1])
+    assert err.mean() <= 5e-5 * scale and err.max() <= 5e-3 * scale, (err.mean() / scale, err.max() / scale)
+    sm, cnt = orc.edge_error(want[0], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert int(trace[0, 0]) == 1 and trace[0, 1] == pytest.approx(sm / cnt, rel=2e-5)

@@ -267,6 +267,7 @@ struct topolow_session {
   // Symmetric sweep (relax_symm.h): one-stage iterations of a whole-matrix fp32 session.
   struct SymState {
     bool allowed = false;          // TOPOLOW_SYMMETRIC=1 (session creation)
+    int min_n = 0;                 // size gate (TOPOLOW_SYMMETRIC_MIN_N at session creation; default kSymMinPoints)
     bool ready = false;            // plan + tile-major copy built for the current block
     int n32 = 0, tiles = 0, grid = 0, n_units = 0;
     DevBuf<uint32_t> tenc;
@@ -674,9 +675,8 @@ template <int DIM> constexpr bool kSymDim = DIM >= 2 && DIM <= 6;
 constexpr int kSymMinPoints = 7168;   // below ~7000 points a resident wave gets fewer than 8 tiles and the row-owner sweep is faster (tests/study/symm_crossover.py)
 
 bool sym_eligible(const topolow_session* s) {
-  static const int min_n = [] { const char* e = getenv("TOPOLOW_SYMMETRIC_MIN_N"); return e ? atoi(e) : kSymMinPoints; }();
   return s->sym.allowed && s->schedule == TOPOLOW_SCHEDULE_SLAB && s->precision == TOPOLOW_PRECISION_F32 &&
-         s->row_begin == 0 && s->row_end == s->n && s->n_push == 0 && s->dim >= 2 && s->dim <= 6 && s->n >= min_n &&
+         s->row_begin == 0 && s->row_end == s->n && s->n_push == 0 && s->dim >= 2 && s->dim <= 6 && s->n >= s->sym.min_n &&
          s->dim == s->udim && !(s->any_threshold && s->dim == 6);   // (the threshold-carrying ERR instance spills at 6)
 }
 
@@ -957,6 +957,8 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     s->fuse_checks = !(fuse != nullptr && fuse[0] == '0');
     const char* symm = getenv("TOPOLOW_SYMMETRIC");
     s->sym.allowed = !(symm != nullptr && symm[0] == '0');   // TOPOLOW_SYMMETRIC=0: row-owner sweeps only
+    const char* symm_min = getenv("TOPOLOW_SYMMETRIC_MIN_N");   // tests lower the size gate to reach the sweep on small problems
+    s->sym.min_n = symm_min != nullptr ? atoi(symm_min) : kSymMinPoints;
     s->enc.alloc((size_t)((s->rows() + kEncRowAlign - 1) / kEncRowAlign * kEncRowAlign) * s->ld);
     const size_t pos_bytes = (size_t)s->pos_rows() * s->dim * s->real_size();
     for (auto& b : s->pos) b.alloc(pos_bytes);
