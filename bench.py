@@ -9,17 +9,21 @@ job's average rate, whatever --steps and --warmup are (the schedule's cost per i
 
   N = 1 : BASELINE.json config 3 -- synthetic N=10 000, 70 % missing, ndim=5, k0=5,
           cooling=0.01, c_repulsion=0.01 -- one embedding on one GPU, targets resident in HBM.
-  N > 1 : default `--mode replicas`: N independent config-3 embeddings, one per GPU, no
-          data-path collective (the reference's own parallel mode) => "scaling": "weak";
-          `--mode sharded`: BASELINE.json config 4 -- synthetic N=50 000, 90 % missing, ndim=3 --
-          ONE embedding row-block sharded over the ranks (all-gather of position slices after
-          every slab stage over RCCL) => "scaling": "strong".
+  N > 1 : one rank per GPU (under the driver's torch.distributed.run, or started by this script when it is
+          launched plainly as `python bench.py --gpus N`).  The line's value is the path BASELINE.json's north_star
+          names for more than one GPU: BASELINE config 4 -- synthetic N=50 000, 90 % missing, ndim=3 -- ONE
+          embedding row-block sharded over the ranks, all-gather of the position slices after every slab stage
+          over RCCL => "scaling": "strong"; `n_gpus` = the devices really used, `rccl_ranks` = the ranks of the
+          RCCL communicator, `roofline.per_gpu_frac` per GPU.  The reference's own parallel mode -- N independent
+          config-3 embeddings, one per GPU, no data-path collective, weak scaling -- follows in the same line as
+          the field `replicas` (`--mode sharded` / `--mode replicas` run only one of the two).  `--gpus 1 --mode
+          sharded` runs the same code at world size 1: the base of the strong-scaling curve.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (slab_stage_pipe_kernel):
 algorithmic bytes per launch = (4*rows*N + 8*N*ndim + 4*N) / stages, divided by its mean
 duration from HIP events recorded on the session stream around every launch in a separate
 profiled pass.  `cpu_baseline` times the CPU oracle (reference schedule, 1 core) on a bounded
-sample of the same workload (N=1 only).
+sample of the same workload (N=1 only); `precision_f64` is the same job in the reference's arithmetic width.
 """
 import argparse
 import json
@@ -49,9 +53,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--stages", type=int, default=0, help="fixed slab stages (0 = adaptive)")
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="multi-GPU mode: independent config-3 embeddings per GPU (weak scaling, "
-                         "default) or ONE row-sharded config-4 embedding (strong scaling)")
+    ap.add_argument("--mode", choices=["auto", "replicas", "sharded"], default="auto",
+                    help="auto: one GPU -> config 3 on that GPU; more than one -> ONE row-sharded config-4 embedding "
+                         "(strong scaling: the line's value) followed by independent config-3 embeddings per GPU "
+                         "(weak scaling: the line's `replicas` field); replicas / sharded: only that one")
+    ap.add_argument("--precision-f64", dest="f64", action="store_true", default=True,
+                    help="also time the same job in f64 (the reference's arithmetic width); --no-precision-f64 skips it")
+    ap.add_argument("--no-precision-f64", dest="f64", action="store_false")
     return ap.parse_args()
 
 
@@ -281,9 +289,38 @@ def run_single(args):
                             "band": 0.04}
         assert q.converged and abs(q.final_mae / ref - 1.0) <= 0.04, out["mae_check"]
 
+    out["dtype_note"] = ("the reference computes in f64 (src/optimization.cpp:134,207-281); value is the fp32 slab path, "
+                         "whose parity band is the header's statement (include/topolow_relax.h); the same job in f64: "
+                         "precision_f64")
+    if args.f64:
+        # the same job, same schedule and labels, in the reference's arithmetic width (f64 instance of the stage
+        # kernel; the symmetric sweep is fp32 only): rate of the whole run to the controller's own stop
+        s64 = _native.Session(n, ndim, precision="f64")
+        s64.set_relabel(2024)
+        s64.load_coo(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.degrees)
+        s64.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        for _warm in (True, False):
+            s64.set_positions(call.initial_positions)
+            s64.begin(1000, k0, cool, c_rep, 1e-4, 5, 3, 2024, args.stages)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            s64.run()
+            it64, _st, _m = s64.sync()
+            torch.cuda.synchronize()
+            sec64 = time.perf_counter() - t
+            q64 = s64.finish()
+        s64.close()
+        out["precision_f64"] = {"iterations_per_s": it64 / sec64, "iterations_run": int(it64), "seconds": sec64,
+                                "final_mae": q64.final_mae, "converged": bool(q64.converged),
+                                "frac": bytes_iter * it64 / sec64 / 1e9 / HBM_PEAK_GBPS,
+                                "vs_f32_whole_run": (it64 / sec64) / (iters_run / whole),
+                                "note": "whole run timed in one piece (compare whole_run); frac = SURVEY 8d's algorithmic "
+                                        "bytes per iteration x rate / 8 TB/s (the f64 path streams the same 4-byte words)"}
+
     if not args.no_cpu_baseline:
         from oracle import topolow_oracle as orc
         ci = args.cpu_iters
+        avail_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
         try:
             os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
         except Exception:
@@ -302,7 +339,15 @@ def run_single(args):
         s.run()
         g = s.finish()
         sm, cnt = orc.edge_error(g.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        cpu_model = None
+        try:
+            with open("/proc/cpuinfo") as fh:
+                cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), None)
+        except OSError:
+            pass
         out["cpu_baseline"] = {"value": ci / cpu_s, "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
+                               "cpus_available_to_this_process": avail_cpus,
                                "sample": f"{ci} iterations of the same N={n} workload (shuffled "
                                          "Gauss-Seidel oracle, f64, g++ -O2), incl. its final MAE check"}
         out["mae_check_early"] = {"iterations": ci, "gpu_slab": g.final_mae, "cpu_oracle": ref.final_mae,
@@ -314,10 +359,30 @@ def run_single(args):
     print(json.dumps(out))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU under torch.distributed.run -- before
+    anything in THIS process touches a GPU -- and pass its line through.  (Counting devices does not initialise the
+    GPU on this image.)"""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if os.environ.get("TOPOLOW_BENCH_OVERSUBSCRIBE") != "1":     # rehearsals put several ranks on one GPU (gloo)
+        assert have >= args.gpus, f"--gpus {args.gpus} asked for, {have} GPU(s) visible"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, cwd=ROOT).returncode)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or args.mode == "sharded":
+    if args.gpus > 1 and world == 1 and not args.devices:
+        launch_ranks(args)
+    if args.gpus > 1 or world > 1 or args.mode == "sharded" or args.devices:
         from topolow_amd import sharded
         sharded.bench_main(args)
     else:

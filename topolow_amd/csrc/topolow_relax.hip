@@ -1286,9 +1286,12 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
       } else {
         const int stages = s->fixed_stages > 0 ? s->fixed_stages : slab_stages_at(iter, s->k_host, s->dim);
         const SlabGeom g = slab_geom(s->n, stages);
-        const bool fuse_now = s->pcheck.active && g.n_stages == 1;
+        const bool sym = g.n_stages == 1 && sym_eligible(s) && sym_available(s);
+        // (the row-owner ERR instance pairs rows two by two: an odd block keeps the separate pass; the symmetric
+        //  sweep's ERR instance has no such rule)
+        const bool fuse_now = s->pcheck.active && g.n_stages == 1 && (sym || s->rows() % 2 == 0);
         if (s->pcheck.active && !fuse_now) flush_pending_check(s);
-        if (g.n_stages == 1 && sym_eligible(s) && sym_available(s)) {   // one sweep over the upper triangle moves both ends of every pair
+        if (sym) {   // one sweep over the upper triangle moves both ends of every pair
           int out = 0;
           while (out == s->cur || out == s->held) ++out;
           TL_DISPATCH_DIM(s->dim, sym_iteration, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host, fuse_now);
@@ -1325,7 +1328,8 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         // one stage next iteration: its kernel reduces this check's MAE (the positions it reads ARE this
         // check's positions) and the separate pass over the block is dropped
         const bool fuse = s->fuse_checks && s->schedule == TOPOLOW_SCHEDULE_SLAB && iter + 1 < s->n_iter &&
-                          s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && s->rows() % 2 == 0 &&
+                          s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 &&
+                          (s->rows() % 2 == 0 || sym_eligible(s)) &&
                           slab_geom(s->n, s->fixed_stages > 0 ? s->fixed_stages
                                                               : slab_stages_at(iter + 1, s->k_host, s->dim)).n_stages == 1;
         if (fuse) s->pcheck = pc;

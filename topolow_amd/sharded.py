@@ -195,11 +195,7 @@ class HipBackend:
         self.torch.cuda.synchronize(self.device)
 
 
-def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, initial_positions,
-                  n_iter: int, k0: float, cooling_rate: float, c_repulsion: float,
-                  relative_epsilon: float = 1e-4, convergence_window: int = 5,
-                  convergence_check_freq: int = 3, seed: int = 0, slab_stages: int = 0,
-                  timers: bool = False, sync_every: int = 8) -> ShardedResult:
+class ShardedRelaxation:
     """The slab relaxation of one embedding over `world` processes (one per GPU).  Mirrors the
     single-GPU session loop (topolow_relax.hip: topolow_session_enqueue) and the reference's iteration
     structure (src/optimization.cpp:193-374 of the reference).
@@ -209,88 +205,131 @@ def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, ini
     controller is replicated (identical inputs, identical decisions), so the ranks learn of a stop by
     reading their own state: every `sync_every`-th check each rank waits for its stream and looks; they all
     see the same state at the same point of the schedule, so they leave the loop together.  Work enqueued
-    after the stop is a no-op on the device (kernels test the stop flag)."""
-    b, e, per = row_block(n, world, rank)
-    if e <= b:
-        raise ValueError(f"row-sharded run: rank {rank} of {world} would own no rows of {n} points "
-                         f"(blocks are whole 8-row workgroups); use at most {-(-n // 8)} ranks")
-    rows_total = per * world
-    pos = [backend.to_device(initial_positions, rows_total), backend.new_positions(rows_total)]
-    cur = 0
-    freq = convergence_check_freq if convergence_check_freq >= 1 else 10
-    backend.begin(initial_positions, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon,
-                  convergence_window, freq, seed)
-    k = k0
-    t_stage = t_gather = t_check = 0.0
-    checks = 0
-    ndim = int(np.asarray(initial_positions).shape[1])
-    fusable = bool(getattr(backend, "can_fuse_checks", False)) and not timers
-    pending = None      # (iter1, k_after, buffer index): a check that rides on the next iteration's single stage
+    after the stop is a no-op on the device (kernels test the stop flag).
 
-    def n_slots_of(it_, k_):
-        st = slab_stages if slab_stages > 0 else _native.slab_stages_at(it_, k_, ndim)
-        return st, len(_native.slab_plan(n, st, seed, it_))
+    `advance(m)` enqueues the next m iterations (bench.py times the job in slices of K iterations this way);
+    `finish()` flushes a pending check, applies the reference's non-finite guard and returns the result."""
 
-    def separate_check(buf, iter1, k_after):
-        total = backend.check_partial(pos[buf])
-        coll.all_reduce_tensor(total)
-        backend.controller_step(total, pos[buf], iter1, k_after)
+    def __init__(self, backend, coll: Collectives, rank: int, world: int, n: int, initial_positions,
+                 n_iter: int, k0: float, cooling_rate: float, c_repulsion: float,
+                 relative_epsilon: float = 1e-4, convergence_window: int = 5,
+                 convergence_check_freq: int = 3, seed: int = 0, slab_stages: int = 0,
+                 timers: bool = False, sync_every: int = 8):
+        b, e, per = row_block(n, world, rank)
+        if e <= b:
+            raise ValueError(f"row-sharded run: rank {rank} of {world} would own no rows of {n} points "
+                             f"(blocks are whole 8-row workgroups); use at most {-(-n // 8)} ranks")
+        self.backend, self.coll, self.rank, self.world, self.n, self.per = backend, coll, rank, world, n, per
+        rows_total = per * world
+        self.pos = [backend.to_device(initial_positions, rows_total), backend.new_positions(rows_total)]
+        self.cur = 0
+        self.freq = convergence_check_freq if convergence_check_freq >= 1 else 10
+        backend.begin(initial_positions, n_iter, k0, cooling_rate, c_repulsion, relative_epsilon,
+                      convergence_window, self.freq, seed)
+        self.n_iter, self.k, self.cooling_rate = n_iter, k0, cooling_rate
+        self.seed, self.slab_stages, self.timers, self.sync_every = seed, slab_stages, timers, sync_every
+        self.t_stage = self.t_gather = self.t_check = 0.0
+        self.checks = 0
+        self.it = 0
+        self.stopped = False
+        self.ndim = int(np.asarray(initial_positions).shape[1])
+        self.fusable = bool(getattr(backend, "can_fuse_checks", False)) and not timers
+        self.pending = None   # (iter1, k_after, buffer index): a check that rides on the next iteration's single stage
 
-    for it in range(n_iter):
-        stages, n_slots = n_slots_of(it, k)
-        fuse_now = pending is not None and n_slots == 1
-        if pending is not None and not fuse_now:
-            separate_check(pending[2], pending[0], pending[1])
-            pending = None
-        for slot in range(n_slots):
-            if timers:   # breakdown pass: host-synchronised, so slower than the timed pass
-                backend.synchronize()
-                t0 = time.perf_counter()
-                backend.stage(pos[cur], pos[cur ^ 1], it, slot, stages, k)
-                backend.synchronize()
-                t1 = time.perf_counter()
-                coll.all_gather_rows(pos[cur ^ 1], per, rank)
-                backend.synchronize()
-                t_stage += t1 - t0
-                t_gather += time.perf_counter() - t1
-            elif fuse_now:
-                # one sweep: the stage, the MAE of the positions it reads (= the pending check), the gather of the
-                # new slices, the all-reduce of the two MAE scalars, the controller -- all enqueued
-                total = backend.stage_fused(pos[cur], pos[cur ^ 1], it, k)
-                coll.all_gather_rows(pos[cur ^ 1], per, rank)
-                coll.all_reduce_tensor(total)
-                backend.controller_step(total, pos[pending[2]], pending[0], pending[1])
-                pending = None
-            else:
-                backend.stage(pos[cur], pos[cur ^ 1], it, slot, stages, k)
-                coll.all_gather_rows(pos[cur ^ 1], per, rank)
-            cur ^= 1
-        k *= (1.0 - cooling_rate)
-        if (it + 1) % freq == 0 or it == n_iter - 1:
-            t0 = time.perf_counter() if timers else 0.0
-            if fusable and it + 1 < n_iter and n_slots_of(it + 1, k)[1] == 1:
-                pending = (it + 1, k, cur)
-            else:
-                separate_check(cur, it + 1, k)
-            checks += 1
-            if timers:
-                backend.synchronize()
-                t_check += time.perf_counter() - t0
-            if checks % max(1, sync_every) == 0 and backend.poll()[0]:
-                break
-    if pending is not None:
-        separate_check(pending[2], pending[0], pending[1])
-        pending = None
-    _stopped, iters_run = backend.poll()
-    bad = int(coll.min_float(float(backend.first_nonfinite() or 0x7FFFFFFF)))
-    if bad != 0x7FFFFFFF:
-        t = -(-bad // 10) * 10                      # reference :359-361: inspected every 10th iteration,
-        if t <= iters_run and not (_stopped and t == iters_run):    # after that iteration's check
-            raise _native.NativeError(
-                _native.ERR_NONFINITE, "Numerical instability at iteration %d. Reduce k0 or c_repulsion." % t)
-    r = backend.finish()
-    return ShardedResult(r.positions, bool(r.converged), int(r.iterations), float(r.final_mae), float(r.final_k),
-                         iters_run, int(r.info.get("n_checks", checks)), t_stage, t_gather, t_check)
+    def _n_slots_of(self, it_, k_):
+        st = self.slab_stages if self.slab_stages > 0 else _native.slab_stages_at(it_, k_, self.ndim)
+        return st, len(_native.slab_plan(self.n, st, self.seed, it_))
+
+    def _separate_check(self, buf, iter1, k_after):
+        total = self.backend.check_partial(self.pos[buf])
+        self.coll.all_reduce_tensor(total)
+        self.backend.controller_step(total, self.pos[buf], iter1, k_after)
+
+    def advance(self, max_iters: int) -> int:
+        """Enqueues up to max_iters further iterations; returns how many (0: the run is over)."""
+        backend, coll, pos, per, rank, timers = self.backend, self.coll, self.pos, self.per, self.rank, self.timers
+        done = 0
+        while done < max_iters and self.it < self.n_iter and not self.stopped:
+            it, k = self.it, self.k
+            stages, n_slots = self._n_slots_of(it, k)
+            fuse_now = self.pending is not None and n_slots == 1
+            if self.pending is not None and not fuse_now:
+                self._separate_check(self.pending[2], self.pending[0], self.pending[1])
+                self.pending = None
+            for slot in range(n_slots):
+                cur = self.cur
+                if timers:   # breakdown pass: host-synchronised, so slower than the timed pass
+                    backend.synchronize()
+                    t0 = time.perf_counter()
+                    backend.stage(pos[cur], pos[cur ^ 1], it, slot, stages, k)
+                    backend.synchronize()
+                    t1 = time.perf_counter()
+                    coll.all_gather_rows(pos[cur ^ 1], per, rank)
+                    backend.synchronize()
+                    self.t_stage += t1 - t0
+                    self.t_gather += time.perf_counter() - t1
+                elif fuse_now:
+                    # one sweep: the stage, the MAE of the positions it reads (= the pending check), the gather of the
+                    # new slices, the all-reduce of the two MAE scalars, the controller -- all enqueued
+                    total = backend.stage_fused(pos[cur], pos[cur ^ 1], it, k)
+                    coll.all_gather_rows(pos[cur ^ 1], per, rank)
+                    coll.all_reduce_tensor(total)
+                    backend.controller_step(total, pos[self.pending[2]], self.pending[0], self.pending[1])
+                    self.pending = None
+                else:
+                    backend.stage(pos[cur], pos[cur ^ 1], it, slot, stages, k)
+                    coll.all_gather_rows(pos[cur ^ 1], per, rank)
+                self.cur ^= 1
+            self.k = k = k * (1.0 - self.cooling_rate)
+            self.it = it + 1
+            done += 1
+            if (it + 1) % self.freq == 0 or it == self.n_iter - 1:
+                t0 = time.perf_counter() if timers else 0.0
+                if self.fusable and it + 1 < self.n_iter and self._n_slots_of(it + 1, k)[1] == 1:
+                    self.pending = (it + 1, k, self.cur)
+                else:
+                    self._separate_check(self.cur, it + 1, k)
+                self.checks += 1
+                if timers:
+                    backend.synchronize()
+                    self.t_check += time.perf_counter() - t0
+                if self.checks % max(1, self.sync_every) == 0 and backend.poll()[0]:
+                    self.stopped = True
+        return done
+
+    def flush(self):
+        """A check still waiting for a sweep to ride on runs as a separate pass (the caller wants the state)."""
+        if self.pending is not None:
+            self._separate_check(self.pending[2], self.pending[0], self.pending[1])
+            self.pending = None
+
+    def finish(self) -> ShardedResult:
+        backend = self.backend
+        self.flush()
+        _stopped, iters_run = backend.poll()
+        bad = int(self.coll.min_float(float(backend.first_nonfinite() or 0x7FFFFFFF)))
+        if bad != 0x7FFFFFFF:
+            t = -(-bad // 10) * 10                      # reference :359-361: inspected every 10th iteration,
+            if t <= iters_run and not (_stopped and t == iters_run):    # after that iteration's check
+                raise _native.NativeError(
+                    _native.ERR_NONFINITE, "Numerical instability at iteration %d. Reduce k0 or c_repulsion." % t)
+        r = backend.finish()
+        return ShardedResult(r.positions, bool(r.converged), int(r.iterations), float(r.final_mae), float(r.final_k),
+                             iters_run, int(r.info.get("n_checks", self.checks)), self.t_stage, self.t_gather,
+                             self.t_check)
+
+
+def relax_sharded(backend, coll: Collectives, rank: int, world: int, n: int, initial_positions,
+                  n_iter: int, k0: float, cooling_rate: float, c_repulsion: float,
+                  relative_epsilon: float = 1e-4, convergence_window: int = 5,
+                  convergence_check_freq: int = 3, seed: int = 0, slab_stages: int = 0,
+                  timers: bool = False, sync_every: int = 8) -> ShardedResult:
+    """One embedding row-sharded over the ranks, from start to the controller's stop (ShardedRelaxation)."""
+    run = ShardedRelaxation(backend, coll, rank, world, n, initial_positions, n_iter, k0, cooling_rate, c_repulsion,
+                            relative_epsilon, convergence_window, convergence_check_freq, seed, slab_stages, timers,
+                            sync_every)
+    run.advance(n_iter)
+    return run.finish()
 
 
 # --------------------------------------------------------------------------------------
@@ -414,9 +453,15 @@ def bench_main(args):
         else:
             dist.init_process_group(backend)
     coll = Collectives(world)
-    mode = getattr(args, "mode", "replicas")
-    if mode == "sharded":
+    mode = getattr(args, "mode", None) or "auto"
+    # auto (the driver's `bench.py --gpus N`): the path BASELINE.json's north_star names for more than one GPU -- ONE
+    # config-4 embedding row-sharded over the ranks (strong scaling) -- is the line's value; the reference's own
+    # parallel mode (independent embeddings, weak scaling) follows as the secondary field "replicas"
+    if mode in ("auto", "sharded"):
         out = _bench_sharded(args, rank, world, local, coll)
+        if mode == "auto" and world > 1 and not getattr(args, "devices", ""):
+            rep = _bench_replicas(args, rank, world, local, coll)
+            out["replicas"] = {k: rep[k] for k in ("value", "unit", "scaling", "ms_per_step", "config", "roofline")}
     else:
         out = _bench_replicas(args, rank, world, local, coll)
     if rank == 0:
@@ -610,10 +655,13 @@ def _bench_sharded_native(args, devices):
 
 
 def _bench_sharded(args, rank, world, local, coll):
-    """Strong scaling: ONE config-4 embedding (N=50 000, 90 % missing, ndim=3) row-sharded over
-    the ranks, all-gather of position slices after every slab stage."""
+    """Strong scaling: ONE config-4 embedding (N=50 000, 90 % missing, ndim=3) row-sharded over the ranks (one
+    process per GPU), all-gather of the position slices after every slab stage over RCCL.  Timed like the one-GPU
+    line (bench.py: run_single): the JOB -- the embedding relaxed to the controller's own stop, unfolding phase
+    included -- in slices of exactly K iterations after W untimed ones, every slice between barrier + device
+    synchronisation on both sides, a slice's time the MAX over the ranks; value = K / mean slice."""
+    import socket
     import torch
-    from . import synthetic
     if world == 1 and getattr(args, "devices", ""):
         return _bench_sharded_native(args, [int(d) for d in args.devices.split(",")])
     n = args.n or 50000
@@ -625,38 +673,99 @@ def _bench_sharded(args, rank, world, local, coll):
     rng = np.random.Generator(np.random.PCG64(999))
     init = np.zeros((n, ndim))
     init[1:] = np.cumsum(rng.uniform(0.0, 2.0 * scale / n, size=(n - 1, ndim)), axis=0)
-    # warm-up + timed run through the same loop
-    relax_sharded(backend, coll, rank, world, n, init, W, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 7,
-                  args.stages)
-    torch.cuda.synchronize()
-    coll.barrier()
-    t0 = time.perf_counter()
-    res = relax_sharded(backend, coll, rank, world, n, init, K, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 7,
-                        args.stages)
-    torch.cuda.synchronize()
-    coll.barrier()
-    elapsed = coll.max_float(time.perf_counter() - t0)
-    kb = max(3, min(K, 9))
-    brk = relax_sharded(backend, coll, rank, world, n, init, kb, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 7,
-                        args.stages, timers=True)
+
+    def new_run(n_iter, window, timers=False):
+        return ShardedRelaxation(backend, coll, rank, world, n, init, n_iter, k0, cool, c_rep, 1e-4, window, 3, 7,
+                                 args.stages, timers=timers)
+
+    def fence():
+        torch.cuda.synchronize()
+        coll.barrier()
+
+    # ---- the job: one embedding to the controller's own stop (first run: code objects, communicator) ----
+    for _warm in (True, False):
+        run = new_run(1000, 5)
+        fence()
+        t0 = time.perf_counter()
+        run.advance(1000)
+        job = run.finish()
+        fence()
+        whole = coll.max_float(time.perf_counter() - t0)
+    n_job = int(job.iterations_run)
+    P = max(1, -(-n_job // K))
+
+    def rotation():
+        if W > 0:                    # W untimed iterations of a throw-away run
+            r0 = new_run(W, 10 ** 9)
+            r0.advance(W)
+            r0.finish()
+        run = new_run(P * K, 10 ** 9)
+        slices = []
+        for _p in range(P):
+            fence()
+            t0 = time.perf_counter()
+            got = run.advance(K)
+            backend.poll()
+            fence()
+            slices.append(coll.max_float(time.perf_counter() - t0))
+            assert got == K, got
+        run.finish()
+        return slices
+
+    rotations = []
+    while (sum(map(sum, rotations)) < args.min_timed or len(rotations) < 3) and len(rotations) < 100:   # same on every rank
+        rotations.append(rotation())
+    rates = [K / float(np.mean(r)) for r in rotations]
+    elapsed = K / float(np.median(rates))
+    slice_rates = K / np.mean(np.array(rotations), axis=0)
+    # ---- breakdown pass over the same iterations, host-synchronised around every stage and every gather ----
+    brk_run = new_run(P * K, 10 ** 9, timers=True)
+    brk_run.advance(P * K)
+    brk = brk_run.finish()
     bytes_iter_rank = backend.session.bytes_per_iteration
     stages = backend.session.stage_launches
+    achieved = bytes_iter_rank * (P * K) / max(brk.stage_seconds, 1e-9) / 1e9
+    mine = dict(rank=rank, host=socket.gethostname(), device=int(local), rows=[int(b), int(e)], achieved=achieved,
+                frac=achieved / 8000.0, stage_ms=1e3 * brk.stage_seconds / (P * K),
+                all_gather_ms=1e3 * brk.gather_seconds / (P * K), check_ms=1e3 * brk.check_seconds / (P * K))
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        coll.dist.all_gather_object(per_rank, mine)
+    backend.session.close()
+    n_gpus = len({(r["host"], r["device"]) for r in per_rank})
     return {
         "metric": "relaxation iterations/sec (NxN pairs)", "value": K / elapsed, "unit": "iterations/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+        "n_gpus": n_gpus, "ranks": world,
+        "collective_backend": (coll.backend if world > 1 else None),
+        "rccl_ranks": world if (world > 1 and coll.backend == "nccl") else 0,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"config 4: ONE embedding, synthetic N={n}, 90% missing, ndim=3, row-block "
-                               f"sharded over {world} GPU(s), all-gather of position slices per slab stage",
+                               f"sharded over {world} rank(s) on {n_gpus} GPU(s), all-gather of position slices per "
+                               "slab stage",
                    "n_points": n, "ndim": ndim, "schedule": "slab", "parallelism": f"rows/{world}",
                    "edges_rank0": n_edges},
-        "roofline": {"bound": "hbm", "achieved": bytes_iter_rank * kb / max(brk.stage_seconds, 1e-9) / 1e9,
-                     "peak": 8000.0, "unit": "GB/s",
-                     "frac": bytes_iter_rank * kb / max(brk.stage_seconds, 1e-9) / 1e9 / 8000.0,
-                     "traffic": None, "kernel": "slab_stage_pipe_kernel<3,float>",
-                     "note": "rank 0: algorithmic bytes of its row block / synchronised stage time"},
-        "breakdown_ms_per_iteration": {"stage": 1e3 * brk.stage_seconds / kb,
-                                       "all_gather": 1e3 * brk.gather_seconds / kb,
-                                       "check": 1e3 * brk.check_seconds / kb},
-        "final_mae": res.final_mae, "stage_launches": int(stages),
+        "timing": {"job_iterations": n_job, "slices_per_rotation": P, "rotations": len(rotations),
+                   "timed_seconds": float(sum(map(sum, rotations))),
+                   "iterations_per_s": {"min": min(rates), "median": float(np.median(rates)), "max": max(rates)},
+                   "iterations_per_s_by_slice": [round(float(x), 1) for x in slice_rates],
+                   "note": "the job (one embedding to the controller's own stop, unfolding phase included) timed in "
+                           "slices of exactly K iterations, each between barrier + device synchronisation on both "
+                           "sides, a slice's time the MAX over ranks, after W untimed iterations of a throw-away run; "
+                           "value = K / mean slice, median over rotations -- the same rule as the one-GPU line"},
+        "whole_run": {"iterations_run": n_job, "seconds": whole, "iterations_per_s": n_job / whole,
+                      "converged": bool(job.converged), "best_iteration": int(job.iterations),
+                      "final_mae": job.final_mae},
+        "roofline": {"bound": "hbm", "achieved": per_rank[0]["achieved"], "peak": 8000.0, "unit": "GB/s",
+                     "frac": per_rank[0]["frac"], "traffic": None, "kernel": "slab_stage_pipe_kernel<3,float>",
+                     "per_gpu_frac": [round(r["frac"], 4) for r in per_rank],
+                     "note": "per rank: algorithmic bytes of its row block over the job / its host-synchronised "
+                             "stage-kernel time (breakdown pass); `frac` is rank 0's"},
+        "breakdown_ms_per_iteration": {"stage": per_rank[0]["stage_ms"], "all_gather": per_rank[0]["all_gather_ms"],
+                                       "check": per_rank[0]["check_ms"],
+                                       "note": "rank 0, breakdown pass (host-synchronised, so the parts add up to "
+                                               "more than ms_per_step)", "per_rank": per_rank},
+        "final_mae": job.final_mae, "stage_launches": int(stages),
     }
