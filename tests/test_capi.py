@@ -166,9 +166,9 @@ def test_stage_kernel_awaits_its_lds_transfers_past_exactly_the_younger_loads():
 
 def test_symmetric_sweep_instances_fit_their_register_budget():
     """Every instance of the symmetric sweep the library launches (ndim 2..6 x {threshold-free, threshold} x {plain,
-    ERR}; the threshold-carrying ones only up to ndim 5: topolow_relax.hip, sym_eligible) must run without scratch and
-    with at least two waves per SIMD; its column reduction must be the 3 x (2 x ndim) single-instruction DPP adds per
-    half tile the kernel's header describes (the optimiser once turned them into v_mov_dpp + v_pk_add pairs)."""
+    ERR}) must run without scratch and with at least two waves per SIMD; its column reduction must be the
+    3 x (2 x ndim) single-instruction DPP adds per half tile the kernel's header describes (the optimiser once turned
+    them into v_mov_dpp + v_pk_add pairs)."""
     import subprocess
     csrc = os.path.join(ROOT, "topolow_amd", "csrc")
     subprocess.run(["make", "-C", csrc, "asm"], check=True, capture_output=True)
@@ -179,8 +179,7 @@ def test_symmetric_sweep_instances_fit_their_register_budget():
         start = text.index("\n" + name + ":")
         end = text.index(".Lfunc_end", start)
         tail = text[end:][:3000]
-        if not (thr == "1" and dim == "6"):
-            assert re.search(r"; ScratchSize: (\d+)", tail).group(1) == "0", name
+        assert re.search(r"; ScratchSize: (\d+)", tail).group(1) == "0", name
         assert int(re.search(r"; Occupancy: (\d+)", tail).group(1)) >= 2, name
         body = text[start:end]
         assert body.count("v_add_f32_dpp") % (3 * 2 * int(dim)) == 0 and "v_add_f32_dpp" in body, name

@@ -35,7 +35,7 @@ def session_run(call, n, dim, symmetric, iters, k0, check_freq=3, stages=1, wind
     return r, trace
 
 
-@pytest.mark.parametrize("dim,thresholds", [(2, 0.0), (3, 0.0), (4, 0.1), (5, 0.0), (5, 0.1), (6, 0.0)])
+@pytest.mark.parametrize("dim,thresholds", [(2, 0.0), (3, 0.0), (4, 0.1), (5, 0.0), (5, 0.1), (6, 0.0), (6, 0.1)])
 def test_symmetric_sweep_equals_the_row_owner_sweep(dim, thresholds):
     n = 7205                                     # not a multiple of 32: phantom rows and columns in the last tiles
     call, _ = pp.random_problem(n, dim, 0.7, seed=50 + dim, thresholds=0.0, n_iter=10, k0=1.5)
@@ -184,7 +184,7 @@ def _model_iterations(call_r, iters, k0, cooling, c_rep):
 
 
 @pytest.mark.parametrize("n", [33, 66, 1000, 7205])
-@pytest.mark.parametrize("dim,thr", [(2, 0.0), (3, 0.15), (4, 0.0), (5, 0.0), (5, 0.15), (6, 0.0)])
+@pytest.mark.parametrize("dim,thr", [(2, 0.0), (3, 0.15), (4, 0.0), (5, 0.0), (5, 0.15), (6, 0.0), (6, 0.15)])
 def test_symmetric_sweep_against_the_model_and_the_oracle(n, dim, thr):
     """n: 33 and 66 leave 31 / 30 phantom rows/columns in the last tile (and fewer tiles than waves), 1000 and 7205 have
     n % 32 = 8 / 5; odd n too (the row-owner ERR instance wants an even block, the sweep's does not); every diagonal tile meets its pairs twice at half weight.  One and seven iterations at one stage:

@@ -11,3 +11,4 @@ run() { timeout -k 5 120 rocprofv3 --pmc $2 --output-format csv -d gpurun_out/sy
 run a "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY"
 run b "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU"
 run c "SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES"
+run d "GRBM_GUI_ACTIVE GRBM_COUNT"

@@ -269,7 +269,7 @@ struct topolow_session {
     bool allowed = false;          // TOPOLOW_SYMMETRIC=1 (session creation)
     int min_n = 0;                 // size gate (TOPOLOW_SYMMETRIC_MIN_N at session creation; default kSymMinPoints)
     bool ready = false;            // plan + tile-major copy built for the current block
-    int n32 = 0, tiles = 0, grid = 0, n_units = 0;
+    int npad = 0, tiles = 0, grid = 0, n_units = 0;   // npad = roundup(n, 64): whole 64-row tiles
     DevBuf<uint32_t> tenc;
     DevBuf<float> rec[2];
     int rec_cur = 0, rec_iter = -1;   // rec[rec_cur] holds the records of iteration rec_iter
@@ -677,7 +677,7 @@ constexpr int kSymMinPoints = 7168;   // below ~7000 points a resident wave gets
 bool sym_eligible(const topolow_session* s) {
   return s->sym.allowed && s->schedule == TOPOLOW_SCHEDULE_SLAB && s->precision == TOPOLOW_PRECISION_F32 &&
          s->row_begin == 0 && s->row_end == s->n && s->n_push == 0 && s->dim >= 2 && s->dim <= 6 && s->n >= s->sym.min_n &&
-         s->dim == s->udim && !(s->any_threshold && s->dim == 6);   // (the threshold-carrying ERR instance spills at 6)
+         s->dim == s->udim;
 }
 
 template <int DIM>
@@ -686,9 +686,9 @@ void sym_prepare(topolow_session* s) {
     throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
   } else {
     auto& y = s->sym;
-    y.n32 = (s->n + kSymTile - 1) & ~(kSymTile - 1);
-    const int T = y.n32 / kSymTile;
-    y.tiles = (int)sym_tile_index(T - 1, T - 1, T) + 1;
+    y.npad = (s->n + kSymRows - 1) & ~(kSymRows - 1);
+    const int TR = y.npad / kSymRows, TC = y.npad / kSymCols;
+    y.tiles = TR * (TR + 1);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int occ = 1 << 30;   // the session's two instances (plain, ERR) share one plan: the smaller occupancy decides the grid
@@ -705,7 +705,7 @@ void sym_prepare(topolow_session* s) {
       probe(&symm_sweep_kernel<DIM, false, true>);
     }
     y.grid = occ * prop.multiProcessorCount;
-    const SymPlan plan = relax_symm_plan(y.n32, y.grid * kSymWaves);
+    const SymPlan plan = relax_symm_plan(y.npad, y.grid * kSymWaves);
     y.n_units = (int)plan.units.size();
     y.units.alloc(plan.units.size());
     y.wave_first.alloc(plan.wave_first.size());
@@ -713,13 +713,13 @@ void sym_prepare(topolow_session* s) {
     HIP_TRY(hipMemcpy(y.units.p, plan.units.data(), plan.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(y.wave_first.p, plan.wave_first.data(), plan.wave_first.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(y.row_units.p, plan.row_units.data(), plan.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
-    y.tenc.alloc((size_t)y.tiles * kSymTile * kSymTile);
-    hipLaunchKernelGGL(symm_tiles_kernel, dim3(y.tiles), dim3(256), 0, s->stream, s->enc.p, s->rows(), s->ld, y.tenc.p, T);
+    y.tenc.alloc((size_t)y.tiles * kSymTileWords);
+    hipLaunchKernelGGL(symm_tiles_kernel, dim3(y.tiles), dim3(256), 0, s->stream, s->enc.p, s->rows(), s->ld, y.tenc.p, TC);
     HIP_TRY(hipGetLastError());
     constexpr int W = SymRec<DIM>::W;
-    for (auto& r : y.rec) r.alloc((size_t)y.n32 * W);
-    y.rowpart.alloc((size_t)y.n_units * kSymTile * DIM);
-    y.colpart.alloc((size_t)T * y.n32 * DIM);
+    for (auto& r : y.rec) r.alloc((size_t)y.npad * W);
+    y.rowpart.alloc((size_t)y.n_units * kSymRows * DIM);
+    y.colpart.alloc((size_t)TR * y.npad * DIM);
     if ((size_t)y.n_units > s->part_sum.n) {   // error partials: one per unit
       HIP_TRY(hipStreamSynchronize(s->stream));
       HIP_TRY(hipStreamSynchronize(s->check_stream));
@@ -758,19 +758,19 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
   } else {
     auto& y = s->sym;
     ProfScope prof(s, err ? &s->prof_sym_err : &s->prof_sym);
-    const int T = y.n32 / kSymTile;
+    const int TC = y.npad / kSymCols;
     if (y.rec_iter != iter) {
       for (int b = 0; b < 2; ++b)   // both buffers need the phantom records; the second one's points are overwritten by the apply
-        hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((y.n32 + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
-                           s->gplus.p, y.rec[b].p, s->n, y.n32, k, s->c_rep);
+        hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((y.npad + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
+                           s->gplus.p, y.rec[b].p, s->n, y.npad, k, s->c_rep);
       y.rec_cur = 0;
     }
     const float* rec = y.rec[y.rec_cur].p;
     float* rec_next = y.rec[y.rec_cur ^ 1].p;
     auto sweep = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec, y.units.p, y.wave_first.p,
-                         y.rowpart.p, y.colpart.p, y.n32, s->state.p, s->part_sum.p, s->part_cnt.p,
-                         s->block_cells / 2ull);
+                         y.rowpart.p, y.colpart.p, y.npad, s->state.p, s->part_sum.p, s->part_cnt.p,
+                         s->block_cells);
     };
     if (s->any_threshold) {
       if (err) sweep(&symm_sweep_kernel<DIM, true, true>); else sweep(&symm_sweep_kernel<DIM, true, false>);
@@ -778,8 +778,8 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
       if (err) sweep(&symm_sweep_kernel<DIM, false, true>); else sweep(&symm_sweep_kernel<DIM, false, false>);
     }
     const double k_next = k * (1.0 - s->cooling);
-    hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(T), dim3(32 * kSymApplyParts), 0, s->stream, rec, rec_next, (float*)pout,
-                       s->gplus.p, y.rowpart.p, y.colpart.p, y.row_units.p, s->n, y.n32, k_next, s->c_rep, iter + 1,
+    hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, s->stream, rec, rec_next, (float*)pout,
+                       s->gplus.p, y.rowpart.p, y.colpart.p, y.row_units.p, s->n, y.npad, k_next, s->c_rep, iter + 1,
                        s->state.p);
     HIP_TRY(hipGetLastError());
     y.rec_cur ^= 1;
