@@ -307,7 +307,7 @@ int main(int argc, char** argv) {
     return 0;
   }
 
-  if (strcmp(mode, "cvsweep") == 0) {
+  if (strcmp(mode, "cvsweep") == 0 || strcmp(mode, "cvsweep_named") == 0) {
     /* "n m F preserve named n_iter window freq eps n_picks n_draws" then row, col, value, code (m each), ndim, k0,
      * cooling_rate, c_repulsion (F each), picks, picks_offset (F + 1), unit_draws, draws_offset (F + 1), seeds (F) */
     typedef SEXP (*call1)(SEXP);
@@ -331,6 +331,20 @@ int main(int argc, char** argv) {
     SET_VECTOR_ELT(a, 16, Rf_ScalarInteger(n_iter)); SET_VECTOR_ELT(a, 17, Rf_ScalarReal(eps));
     SET_VECTOR_ELT(a, 18, Rf_ScalarInteger(window)); SET_VECTOR_ELT(a, 19, Rf_ScalarInteger(freq));
     fclose(f);
+    if (strcmp(mode, "cvsweep_named") == 0) {
+      /* the same arguments as a NAMED list in reverse order: the entry must find them by name */
+      static const char* const arg_names[20] = {
+          "row", "col", "value", "code", "n", "named", "preserve_order", "ndim", "k0", "cooling_rate", "c_repulsion",
+          "picks", "picks_offset", "unit_draws", "draws_offset", "seeds", "n_iter", "relative_epsilon",
+          "convergence_counter", "convergence_check_freq"};
+      SEXP b = Rf_allocVector(VECSXP, 20), nm = Rf_allocVector(STRSXP, 20);
+      for (int q = 0; q < 20; ++q) {
+        SET_VECTOR_ELT(b, 19 - q, VECTOR_ELT(a, q));
+        SET_STRING_ELT(nm, 19 - q, Rf_mkChar(arg_names[q]));
+      }
+      Rf_setAttrib(b, R_NamesSymbol, nm);
+      a = b;
+    }
     if (setjmp(error_jmp) != 0) {
       printf("{\"error\": \"%s\", ", error_msg);
       print_tail();

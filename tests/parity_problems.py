@@ -179,6 +179,13 @@ PROBLEMS = {
     "syn2000_ndim3_sparse": dict(fn=lambda: _syn_lowdim(2000, 3, 0.9, 12), doc="random_problem(2000, 3, 0.9, seed=12, "
                                  "n_iter=1000, k0=5, cool=0.01, c_rep=0.01): BASELINE config 4's shape (ndim 3, 90 % "
                                  "missing) at a size the oracle finishes"),
+    # the same two shapes at a size that takes the symmetric sweep (>= 7 168 points): pinned before any change of the
+    # schedule's constants (unfolding iterations, k / S bound) is adopted
+    "syn7168_ndim2": dict(fn=lambda: _syn_lowdim(7168, 2, 0.7, 21), doc="random_problem(7168, 2, 0.7, seed=21, n_iter=1000, "
+                          "k0=5, cool=0.01, c_rep=0.01)"),
+    "syn7168_ndim3_sparse": dict(fn=lambda: _syn_lowdim(7168, 3, 0.9, 22), doc="random_problem(7168, 3, 0.9, seed=22, "
+                                 "n_iter=1000, k0=5, cool=0.01, c_rep=0.01): BASELINE config 4's shape above the "
+                                 "symmetric sweep's size gate"),
     "h3n2_ndim4": dict(fn=lambda: (h3n2_call(4), None), doc="Smith-2004 H3N2 panel (tests/golden/"
                        "h3n2_distances.csv), ndim 4, published parameters, start positions default_rng(7)"),
     "h3n2_ndim5": dict(fn=lambda: (h3n2_call(5), None), doc="the same, ndim 5 (BASELINE config 2)"),

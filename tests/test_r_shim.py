@@ -209,15 +209,17 @@ def test_cv_sweep_entry_equals_the_library_sweep(harness, tmp_path):
     lines = ["mode cvsweep", f"{n} {rows.size} {F} 0 0 80 5 3 1e-4 {int(p_off[-1])} {int(d_off[-1])}", _fmt(rows), _fmt(cols),
              _fmt(vals), _fmt(codes), _fmt(ndim), _fmt(k0), _fmt(cool), _fmt(crep), _fmt(np.concatenate(picks)), _fmt(p_off),
              " ".join(repr(float(x)) for u in draws for x in u.ravel()), _fmt(d_off), _fmt(seeds)]
-    path = tmp_path / "sweep.txt"
-    path.write_text("\n".join(lines) + "\n")
-    res = subprocess.run([harness, str(path)], capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0, res.stderr
-    got = json.loads(res.stdout)
     hsum, hcnt, its, conv, ec, _secs = want
-    assert got["holdout_sum_abs"] == hsum.tolist() and got["holdout_count"] == hcnt.tolist()
-    assert got["iterations"] == its.tolist() and got["converged"] == conv.tolist() and got["error_code"] == ec.tolist()
-    assert got["protect_depth"] == 0 and all(c > 0 for c in hcnt)
+    for mode in ("cvsweep", "cvsweep_named"):      # positional list; the same arguments NAMED, in reverse order
+        lines[0] = "mode " + mode
+        path = tmp_path / (mode + ".txt")
+        path.write_text("\n".join(lines) + "\n")
+        res = subprocess.run([harness, str(path)], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        got = json.loads(res.stdout)
+        assert got["holdout_sum_abs"] == hsum.tolist() and got["holdout_count"] == hcnt.tolist()
+        assert got["iterations"] == its.tolist() and got["converged"] == conv.tolist() and got["error_code"] == ec.tolist()
+        assert got["protect_depth"] == 0 and all(c > 0 for c in hcnt)
 
 
 @pytest.mark.gpu

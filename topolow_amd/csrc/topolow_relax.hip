@@ -451,6 +451,9 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
       case 22: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 4>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
       case 23: launch_stage_pipe<DIM, float, StageCfg<256, 2, 256, 1, 5>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
       case 24: launch_stage_pipe<DIM, float, StageCfg<256, 2, 512, 1, 7>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      case 25: launch_stage_pipe<DIM, float, StageCfg<512, 2, 768, 0, 4>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      case 27: launch_stage_pipe<DIM, float, StageCfg<256, 2, 1024, 1, 4>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
+      case 28: launch_stage_pipe<DIM, float, StageCfg<512, 2, 512, 0, 4>>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
       default: launch_stage_pipe<DIM, float, CfgProd>(s, pin, pout, st, rg, iter1, k, push, n_push, err); break;
     }
 #else

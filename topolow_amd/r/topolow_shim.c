@@ -355,7 +355,8 @@ SEXP _topolow_cv_fold(SEXP rowSEXP, SEXP colSEXP, SEXP valueSEXP, SEXP codeSEXP,
   return out;
 }
 
-/* A whole cross-validation sweep (topolow_cv_sweep): ONE argument, a list of 20 in this order --
+/* A whole cross-validation sweep (topolow_cv_sweep): ONE argument, a list of 20 -- NAMED (any order; the names are
+ * those below, kCvSweepArgs) or unnamed in this order --
  *   row, col (integer, 0-based), value (double), code (integer): the non-NA cells of the matrix, column-major order;
  *   n; named (logical); preserve_order (logical);
  *   ndim (integer), k0, cooling_rate, c_repulsion (double): one entry per fold;
@@ -372,34 +373,65 @@ static int64_t* as_i64(SEXP v, int64_t* len) {
   return out;
 }
 
-SEXP _topolow_cv_sweep(SEXP a) {
+static const char* const kCvSweepArgs[20] = {
+    "row", "col", "value", "code", "n", "named", "preserve_order", "ndim", "k0", "cooling_rate", "c_repulsion", "picks",
+    "picks_offset", "unit_draws", "draws_offset", "seeds", "n_iter", "relative_epsilon", "convergence_counter",
+    "convergence_check_freq"};
+
+/* The 20 arguments of a sweep in kCvSweepArgs order: by name when the list carries names (every one of the 20 must
+ * be there, extra or misspelt names are errors), by position otherwise. */
+static SEXP cv_sweep_args(SEXP a) {
   if (!Rf_isNewList(a) || Rf_length(a) != 20) Rf_error("cv_sweep: one list of 20 elements expected");
+  SEXP names = Rf_getAttrib(a, R_NamesSymbol);
+  if (names == R_NilValue) return a;
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 20));
+  int found[20];
+  memset(found, 0, sizeof found);
+  for (int q = 0; q < 20; ++q) {
+    const char* nm = CHAR(STRING_ELT(names, q));
+    int at = -1;
+    for (int j = 0; j < 20; ++j)
+      if (strcmp(nm, kCvSweepArgs[j]) == 0) at = j;
+    if (at < 0 || found[at]) {
+      UNPROTECT(1);
+      Rf_error("cv_sweep: unknown or repeated argument name '%s'", nm);
+    }
+    found[at] = 1;
+    SET_VECTOR_ELT(out, at, VECTOR_ELT(a, q));
+  }
+  UNPROTECT(1);     /* (nothing below allocates R memory before the elements have been read) */
+  return out;
+}
+
+SEXP _topolow_cv_sweep(SEXP arg) {
+  SEXP a = PROTECT(cv_sweep_args(arg));
+#define CV_SWEEP_FAIL(msg) do { UNPROTECT(1); Rf_error(msg); } while (0)
   SEXP row = VECTOR_ELT(a, 0), col = VECTOR_ELT(a, 1), value = VECTOR_ELT(a, 2), code = VECTOR_ELT(a, 3);
   if (!Rf_isInteger(row) || !Rf_isInteger(col) || !Rf_isReal(value) || !Rf_isInteger(code))
-    Rf_error("row, col, code must be integer and value double");
+    CV_SWEEP_FAIL("row, col, code must be integer and value double");
   const int n = Rf_asInteger(VECTOR_ELT(a, 4));
   const int64_t m = (int64_t)XLENGTH(row);
   if (n < 1 || XLENGTH(col) != m || XLENGTH(value) != m || XLENGTH(code) != m)
-    Rf_error("cell columns must have one length and n must be positive");
+    CV_SWEEP_FAIL("cell columns must have one length and n must be positive");
   SEXP ndim = VECTOR_ELT(a, 7), k0 = VECTOR_ELT(a, 8), cool = VECTOR_ELT(a, 9), crep = VECTOR_ELT(a, 10);
   const int F = Rf_length(ndim);
   if (!Rf_isInteger(ndim) || !Rf_isReal(k0) || !Rf_isReal(cool) || !Rf_isReal(crep) || Rf_length(k0) != F ||
       Rf_length(cool) != F || Rf_length(crep) != F || !Rf_isReal(VECTOR_ELT(a, 13)))
-    Rf_error("per-fold parameters: integer ndim, double k0 / cooling_rate / c_repulsion / unit_draws of one length");
+    CV_SWEEP_FAIL("per-fold parameters: integer ndim, double k0 / cooling_rate / c_repulsion / unit_draws of one length");
   int64_t np = 0, npo = 0, ndo = 0, ns = 0;
   int64_t* picks = as_i64(VECTOR_ELT(a, 11), &np);
   int64_t* p_off = as_i64(VECTOR_ELT(a, 12), &npo);
   int64_t* d_off = as_i64(VECTOR_ELT(a, 14), &ndo);
   int64_t* seeds_i = as_i64(VECTOR_ELT(a, 15), &ns);
   if (npo != F + 1 || ndo != F + 1 || ns != F || p_off[F] != np || d_off[F] != (int64_t)XLENGTH(VECTOR_ELT(a, 13)))
-    Rf_error("offsets must have one entry per fold plus one and end at the lengths of picks / unit_draws");
+    CV_SWEEP_FAIL("offsets must have one entry per fold plus one and end at the lengths of picks / unit_draws");
   uint64_t* seeds = (uint64_t*)R_alloc(F > 0 ? (size_t)F : 1, sizeof(uint64_t));
   for (int f = 0; f < F; ++f) seeds[f] = (uint64_t)seeds_i[f];
   int64_t* pos_of = (int64_t*)R_alloc((size_t)n * n, sizeof(int64_t));
   int64_t* by_row = (int64_t*)R_alloc(m > 0 ? (size_t)m : 1, sizeof(int64_t));
   int64_t* row_ptr = (int64_t*)R_alloc((size_t)n + 1, sizeof(int64_t));
   if (topolow_cell_list_index(n, m, INTEGER(row), INTEGER(col), pos_of, by_row, row_ptr) != TOPOLOW_OK)
-    Rf_error("cell list: row / col out of range");
+    CV_SWEEP_FAIL("cell list: row / col out of range");
   topolow_cell_list cells;
   memset(&cells, 0, sizeof cells);
   cells.n = n; cells.n_cells = m;
@@ -423,13 +455,14 @@ SEXP _topolow_cv_sweep(SEXP a) {
                                   opt_int("topolow.device", -1), REAL(hs), hcount, INTEGER(it), INTEGER(cv), INTEGER(ec),
                                   &secs, err, sizeof err);
   if (rc != TOPOLOW_OK) {
-    UNPROTECT(6);
+    UNPROTECT(7);
     Rf_error("%s", err[0] ? err : "topolow_cv_sweep failed");
   }
   for (int f = 0; f < F; ++f) REAL(hc)[f] = (double)hcount[f];
   SET_VECTOR_ELT(out, 0, hs); SET_VECTOR_ELT(out, 1, hc); SET_VECTOR_ELT(out, 2, it); SET_VECTOR_ELT(out, 3, cv);
   SET_VECTOR_ELT(out, 4, ec); SET_VECTOR_ELT(out, 5, Rf_ScalarReal(secs));
-  UNPROTECT(6);
+  UNPROTECT(7);
+#undef CV_SWEEP_FAIL
   return out;
 }
 
