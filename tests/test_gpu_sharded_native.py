@@ -165,3 +165,90 @@ def test_sharded_fuzz_equals_single_session(thread_per_block, monkeypatch):
         assert got.final_mae == pytest.approx(one.final_mae, rel=1e-5, abs=1e-12)
         done += 1
     assert done >= 6
+
+
+# ----------------------------------------------------------------------------------------
+# one-stage iterations as the symmetric sweep sharded over the row-block sessions (csrc/relax_symm.h: segments of the
+# tile list, folded partials peer-stored into the owners' inboxes, the owners move their points)
+# ----------------------------------------------------------------------------------------
+def _sessions(call, n, dim, blocks, env):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ss = []
+        for rb, re_ in _native.shard_rows(n, blocks):
+            s = _native.Session(n, dim, rb, re_, precision="f32")
+            s.load_coo(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh, call.degrees)
+            lo, hi = np.minimum(call.edge_i, call.edge_j), np.maximum(call.edge_i, call.edge_j)
+            own = np.where((lo + hi) % 2 == 0, lo, hi)          # the parity rule of the sharded MAE (include/topolow_relax.h)
+            m = (own >= rb) & (own < re_)
+            s.set_edges(call.edge_i[m], call.edge_j[m], call.edge_dist[m], call.edge_thresh[m])
+            ss.append(s)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return ss
+
+
+@pytest.mark.parametrize("dim,thr", [(3, 0.0), (5, 0.0), (5, 0.15), (2, 0.0)])
+@pytest.mark.parametrize("thread_per_block", ["0", "1"])
+def test_sharded_symmetric_sweep_equals_the_single_block(dim, thr, thread_per_block, monkeypatch):
+    """2, 3 and 4 row blocks on one device, one-stage iterations as the sharded symmetric sweep, against ONE block (the
+    whole matrix, plain symmetric sweep): the same pairs, the same arithmetic per pair; the partial sums are grouped
+    by segment, so positions agree to the fp32 summation band of test_symmetric_sweep_equals_the_row_owner_sweep
+    (2e-5 of the coordinate scale per iteration), every check's MAE to 2e-6, same verdicts.  2 973 points: the
+    segments cut tile-rows in the middle and the blocks' row ranges (multiples of 8) do not coincide with tile-rows."""
+    monkeypatch.setenv("TOPOLOW_SHARD_THREAD_PER_BLOCK", thread_per_block)
+    n = 2973
+    call, _ = pp.random_problem(n, dim, 0.7, seed=40 + dim, thresholds=0.0, n_iter=10, k0=1.5)
+    if thr > 0:
+        rng = np.random.default_rng(3)
+        code = rng.choice([0, 1, -1], size=call.edge_thresh.shape[0], p=[1 - thr, thr / 2, thr / 2])
+        call.edge_thresh[:] = code.astype(call.edge_thresh.dtype)
+    env = {"TOPOLOW_SYMMETRIC": "1", "TOPOLOW_SYMMETRIC_MIN_N": "0"}
+    scale = float(np.abs(call.initial_positions).max())
+    iters = 9                                   # checks at 3 and 6 ride on the sweeps of 4 and 7, the last one is separate
+    runs = {}
+    for blocks in (1, 2, 3, 4):
+        ss = _sessions(call, n, dim, blocks, env)
+        r = _native.run_sharded(ss, call.initial_positions, iters, 1.5, 0.01, 0.01, 1e-12, 10 ** 9, 3, 5, 1)
+        runs[blocks] = (r, ss[0].check_trace())
+        for s in ss:
+            s.close()
+    one, t_one = runs[1]
+    assert t_one.shape[0] == 3
+    for blocks in (2, 3, 4):
+        got, tr = runs[blocks]
+        assert np.abs(got.positions - one.positions).max() <= 2e-5 * scale * iters, blocks
+        assert tr.shape == t_one.shape and np.array_equal(tr[:, 0], t_one[:, 0])
+        assert np.allclose(tr[:, 1], t_one[:, 1], rtol=2e-6, atol=0), (blocks, tr[:, 1], t_one[:, 1])
+        assert got.iterations == one.iterations and got.final_mae == pytest.approx(one.final_mae, rel=2e-6)
+        assert got.info["groups"] == (blocks if thread_per_block == "1" else 1)
+    # ... and the sharded sweep against the row-owner engine (TOPOLOW_SHARD_SYMMETRIC=0): same band
+    monkeypatch.setenv("TOPOLOW_SHARD_SYMMETRIC", "0")
+    ss = _sessions(call, n, dim, 2, env)
+    ro = _native.run_sharded(ss, call.initial_positions, iters, 1.5, 0.01, 0.01, 1e-12, 10 ** 9, 3, 5, 1)
+    for s in ss:
+        s.close()
+    assert np.abs(ro.positions - runs[2][0].positions).max() <= 2e-5 * scale * iters
+
+
+def test_sharded_symmetric_sweep_whole_run_through_the_one_shot_entry(monkeypatch):
+    """The production entry over four blocks on a problem above the size gate: multi-stage iterations on the row-owner
+    kernel, one-stage iterations on the sharded symmetric sweep, fused checks, early stop -- against the one-session
+    run of the same seed (same schedule; only fp32 summation order differs): same stop within two checks, same MAE."""
+    call, _ = pp.cfg3_generator(7400)
+    one = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=3)
+    got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=3, devices=[0, 0, 0, 0])
+    monkeypatch.setenv("TOPOLOW_SHARD_SYMMETRIC", "0")
+    row = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=3, devices=[0, 0, 0, 0])
+    for x in (got, row):
+        assert x.converged and one.converged
+        assert abs(x.iterations - one.iterations) <= 6
+        assert x.final_mae == pytest.approx(one.final_mae, rel=1e-3)
+    sm, cnt = orc.edge_error(got.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert got.final_mae == pytest.approx(sm / cnt, rel=2e-5)

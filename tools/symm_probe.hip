@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(ref_kernel<DIM>, dim3((n + 63) / 64), dim3(64), 0, 0, d_enc, ld, d_pos, d_g, n, k, c_rep, d_ref, d_err);
   CK(hipDeviceSynchronize()); printf("ref done\n");
   hipLaunchKernelGGL((symm_sweep_kernel<DIM, false, true>), dim3(grid), dim3(64 * kSymWaves), 0, 0, d_tenc, d_rec, d_units,
-                     d_wf, d_rowp, d_colp, npad, (const RunState*)nullptr, d_psum, d_pcnt, 0ull);
+                     d_wf, d_rowp, d_colp, npad, (const RunState*)nullptr, d_psum, d_pcnt, 0ull, 0);
   CK(hipDeviceSynchronize()); printf("sweep done\n");
   hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, npad,
                      k * 0.99, c_rep, 1, (RunState*)nullptr);
@@ -140,7 +140,7 @@ int main(int argc, char** argv) {
   };
   auto sweep = [&](auto err_tag) {
     hipLaunchKernelGGL((symm_sweep_kernel<DIM, false, decltype(err_tag)::value>), dim3(grid), dim3(64 * kSymWaves), 0, 0, d_tenc, d_rec,
-                       d_units, d_wf, d_rowp, d_colp, npad, (const RunState*)nullptr, d_psum, d_pcnt, 0ull);
+                       d_units, d_wf, d_rowp, d_colp, npad, (const RunState*)nullptr, d_psum, d_pcnt, 0ull, 0);
   };
   auto apply = [&]() {
     hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, 0, d_rec, d_rec2, d_out, d_g, d_rowp, d_colp, d_ru, n, npad,

@@ -78,6 +78,7 @@ struct ShardedRun {
   HipError first_error{TOPOLOW_OK, ""};
   int warmup_iters = 0;          // > 0: the clock of `timed_seconds` starts when these iterations have drained
   double t_timed0 = 0.0;
+  bool pair_sharded = false;     // one-stage iterations run as the symmetric sweep sharded over the sessions (relax_symm.h)
   // results of the loop
   int iters_enqueued = 0;
   bool interrupted = false;
@@ -133,6 +134,10 @@ inline void sharded_worker(ShardedRun& R, int r) {
   };
   bool fusable = true;
   for (topolow_session* s : R.ss) fusable = fusable && can_fuse(s);
+  // one-stage iterations as the sharded symmetric sweep: its ERR instance has no even-rows rule
+  bool fusable_pair = R.pair_sharded;
+  for (topolow_session* s : R.ss)
+    fusable_pair = fusable_pair && s->fuse_checks && s->dense_mae && s->precision == TOPOLOW_PRECISION_F32;
   auto separate_check = [&](int buf, int iter1, double k_after) -> bool {
     const int tab = (int)(n_check & 1) * R.P;
     ++n_check;
@@ -168,6 +173,36 @@ inline void sharded_worker(ShardedRun& R, int r) {
     if (pend && !fuse_now) { if (!separate_check(pend_buf, pend_iter1, pend_k)) return; pend = false; }
     const int tab = (int)(n_check & 1) * R.P;   // the table of the check this sweep carries, if any
     if (fuse_now) ++n_check;
+    if (R.pair_sharded && geo.n_stages == 1) {
+      // every session sweeps its segment of the tile list and folds its partials into the owners' inboxes; barrier;
+      // the owners move their points and store them into every session's next buffer; barrier
+      const int nxt = (cur + 1) % 3;
+      for (int b : G.blocks) {
+        topolow_session* s = R.ss[b];
+        TL_DISPATCH_DIM(s->dim, sym_sharded_sweep, s, s->pos[cur].p, iter, k, fuse_now);
+        if (fuse_now) {
+          ProfScope prof(s, &s->prof_check);
+          hipLaunchKernelGGL(reduce_push_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
+                             s->sym.n_units, s->rsum_tab.p, s->rcnt_tab.p, s->n_ranks, tab + s->rank, s->state.p);
+          HIP_TRY(hipGetLastError());
+        }
+      }
+      if (!exchange()) return;
+      if (fuse_now) {
+        for (int b : G.blocks) {
+          topolow_session* s = R.ss[b];
+          ProfScope prof(s, &s->prof_check);
+          launch_controller(s, s->pos[pend_buf].p, pend_iter1, pend_k, s->rank_sum.p + tab, s->rank_cnt.p + tab, s->n_ranks);
+        }
+        pend = false;
+      }
+      for (int b : G.blocks) {
+        topolow_session* s = R.ss[b];
+        TL_DISPATCH_DIM(s->dim, sym_sharded_apply, s, s->pos[cur].p, s->pos[nxt].p, s->push_tab[nxt].p, iter);
+      }
+      if (!exchange()) return;
+      cur = nxt;
+    } else
     for (int slot = 0; slot < geo.n_stages; ++slot) {
       const SlabRanges rg = slab_ranges(geo, lead->seed, iter, slot);
       for (int b : G.blocks) {
@@ -202,7 +237,7 @@ inline void sharded_worker(ShardedRun& R, int r) {
     }
     k *= (1.0 - R.cooling);   // reference :289
     if ((iter + 1) % R.check_freq == 0 || iter == R.n_iter - 1) {   // reference :294
-      const bool fuse = fusable && iter + 1 < R.n_iter &&
+      const bool fuse = (fusable || fusable_pair) && iter + 1 < R.n_iter &&
                         slab_geom(lead->n, R.fixed_stages > 0 ? R.fixed_stages
                                                               : slab_stages_at(iter + 1, k, lead->dim)).n_stages == 1;
       if (fuse) { pend = true; pend_iter1 = iter + 1; pend_k = k; pend_buf = cur; }

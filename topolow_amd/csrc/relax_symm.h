@@ -68,30 +68,45 @@ struct SymPlan {
   std::vector<int> wave_first;
   std::vector<int2> row_units;
 };
-inline SymPlan relax_symm_plan(int npad, int n_waves) {
+// The plan of the tiles [t0, t1) of the tile-row-major list (a SEGMENT: the whole list on one GPU, one of P equal
+// runs of it when the sweep is sharded over P row-block sessions): tile0 counts from t0, row_units is indexed by
+// R - r_first and covers the tile-rows [r_first, r_last] that hold a tile of the segment.
+inline SymPlan relax_symm_plan(int npad, int n_waves, long long t0 = 0, long long t1 = -1, int* r_first = nullptr,
+                               int* r_last = nullptr) {
   SymPlan P;
   const int TR = npad / kSymRows, TC = npad / kSymCols;
-  const long long total = (long long)TR * (TR + 1);
-  P.row_units.resize(TR);
+  if (t1 < 0) t1 = (long long)TR * (TR + 1);
+  const long long total = t1 - t0;
+  int rf = -1, rl = -1;
+  for (int R = 0; R < TR; ++R) {
+    const long long a = sym_tile_index(R, 2 * R, TC), b = a + (TC - 2 * R);
+    if (b > t0 && a < t1) { if (rf < 0) rf = R; rl = R; }
+  }
+  if (r_first) *r_first = rf;
+  if (r_last) *r_last = rl;
   P.wave_first.assign(n_waves + 1, 0);
+  if (rf < 0) return P;
+  P.row_units.resize(rl - rf + 1);
   long long done = 0;   // tiles handed out so far
   int w = 0;
   long long w_end = (total * (w + 1) + n_waves - 1) / n_waves;   // wave w's run ends at tile w_end (exclusive)
-  for (int R = 0; R < TR; ++R) {
-    P.row_units[R].x = (int)P.units.size();
-    int j = 2 * R;
-    while (j < TC) {
+  for (int R = rf; R <= rl; ++R) {
+    P.row_units[R - rf].x = (int)P.units.size();
+    const long long row0 = sym_tile_index(R, 2 * R, TC);
+    int j = 2 * R + (int)std::max<long long>(0, t0 - row0);
+    const int j_end = 2 * R + (int)std::min<long long>(TC - 2 * R, t1 - row0);
+    while (j < j_end) {
       while (done >= w_end && w + 1 < n_waves) {
         ++w;
         P.wave_first[w] = (int)P.units.size();
         w_end = (total * (w + 1) + n_waves - 1) / n_waves;
       }
-      const int take = (int)std::min<long long>(TC - j, std::max<long long>(w_end - done, 1));
-      P.units.push_back({R, j, j + take, (int)sym_tile_index(R, j, TC)});
+      const int take = (int)std::min<long long>(j_end - j, std::max<long long>(w_end - done, 1));
+      P.units.push_back({R, j, j + take, (int)(sym_tile_index(R, j, TC) - t0)});
       j += take;
       done += take;
     }
-    P.row_units[R].y = (int)P.units.size() - P.row_units[R].x;
+    P.row_units[R - rf].y = (int)P.units.size() - P.row_units[R - rf].x;
   }
   for (int q = w + 1; q <= n_waves; ++q) P.wave_first[q] = (int)P.units.size();
   return P;
@@ -183,7 +198,8 @@ __device__ __forceinline__ void sym_pair(const float (&pc)[DIM], float ksc, floa
 // rec    : npad records (SymRec<DIM>::W floats each), npad = roundup(n, 64); records >= n are the phantom point
 // rowpart: [n_units][64][DIM]   row sums of a unit            (sum of dx * coef over the unit's columns)
 // colpart: [n_tile_rows][npad][DIM]  column sums of a tile-row (sum of dx * coef_c over the tile-row's 64 rows),
-//          meaningful for the columns right of the tile-row's diagonal square only
+//          meaningful for the columns right of the tile-row's diagonal square only; tile-row R is row R - col_row0
+//          (a segment's first tile-row; 0 for the whole triangle)
 // part_sum / part_cnt: [n_units]  ERR launches: TWICE the sum |t - r| and TWICE the count over the unit's contributing
 //          pairs, as the row-owner ERR instance leaves them (it meets every pair twice; the ratio is the MAE): a pair of
 //          the diagonal square is met from both sides, possibly by two units, and counts once per visit, every other pair
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
     const uint32_t* __restrict__ enc, const float* __restrict__ rec, const SymUnit* __restrict__ units,
     const int* __restrict__ wave_first, float* __restrict__ rowpart, float* __restrict__ colpart, int npad,
     const RunState* st, double* __restrict__ part_sum, unsigned long long* __restrict__ part_cnt,
-    unsigned long long fixed_cnt) {
+    unsigned long long fixed_cnt, int col_row0) {
   if (st != nullptr && st->stopped) return;
 #ifdef TOPOLOW_SYM_STAMPS   // diagnostic build (tools/symm_probe.hip): shader clock against the 100-MHz real-time counter, per wave
   const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(enc) + (size_t)tile0 * kSymTileWords, 0, (J1 - J0) * kSymTileWords * 4, 0x00020000);
     // the tile-row's column partials as one buffer; lanes a != 0 get an offset past its end
-    const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(colpart + (size_t)R * npad * DIM, 0, npad * DIM * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(colpart + (size_t)(R - col_row0) * npad * DIM, 0, npad * DIM * 4, 0x00020000);
     const int col_off = a == 0 ? 4 * b * DIM * 4 : 0x40000000;
     // the words of half tile (J, h): four 16-byte loads, one per row pair
     auto request = [&](int J, int h, u32x4 (&dst)[4]) {
@@ -495,12 +511,15 @@ __global__ __launch_bounds__(256) void symm_records_kernel(const float* __restri
   for (int d = DIM + 2; d < W; ++d) r[d] = 0.0f;
 }
 
-// The tile-major copy of the upper triangle from the row-major encoded block (rows x ld words, rows >= n): one
-// workgroup per tile, 8 words per thread; rows and columns past the block's end read as unmeasured.
-__global__ __launch_bounds__(256) void symm_tiles_kernel(const uint32_t* __restrict__ enc, int rows, int ld,
-                                                        uint32_t* __restrict__ tenc, int TC) {
+// The tile-major copy of tiles [t_first, t_first + gridDim.x) of the upper triangle from the row-major encoded matrix,
+// which lies in n_src row blocks (one on a single GPU; the row-block sessions of a sharded run otherwise -- on other
+// GPUs of the node their words arrive as peer reads, once per loaded matrix): block q holds rows [row0[q], row0[q + 1])
+// of ld words each.  One workgroup per tile, 8 words per thread; rows and columns past the matrix read as unmeasured.
+__global__ __launch_bounds__(256) void symm_tiles_kernel(const uint32_t* const* __restrict__ src, const int* __restrict__ row0,
+                                                        int n_src, int ld, uint32_t* __restrict__ tenc, int TC,
+                                                        long long t_first) {
   // tile index -> (R, J): tile-row R starts at R TC - R (R - 1) and is TC - 2 R tiles long
-  const long long t = blockIdx.x;
+  const long long t = t_first + blockIdx.x;
   int R = 0;
   {
     // largest R with R (TC + 1) - R^2 <= t  (closed form, then corrected for rounding)
@@ -511,16 +530,104 @@ __global__ __launch_bounds__(256) void symm_tiles_kernel(const uint32_t* __restr
     while ((long long)(R + 1) * TC - (long long)(R + 1) * R <= t) ++R;
   }
   const int J = 2 * R + (int)(t - ((long long)R * TC - (long long)R * (R - 1)));
-  uint32_t* dst = tenc + (size_t)t * kSymTileWords;
+  uint32_t* dst = tenc + (size_t)blockIdx.x * kSymTileWords;
+  const int rows = row0[n_src];
 #pragma unroll
   for (int q = 0; q < kSymTileWords / 256; ++q) {
     const int cell = threadIdx.x + q * 256;          // 64 x 32 cells, row-major: coalesced reads of 128 bytes per row
     const int r = cell >> 5, c = cell & 31;
     const int row = R * kSymRows + r, col = J * kSymCols + c;
-    const uint32_t w = (row < rows && col < ld) ? enc[enc_index(row, col, ld)] : kInfWord;
+    uint32_t w = kInfWord;
+    if (row < rows && col < ld) {
+      int blk = 0;
+      while (blk + 1 < n_src && row >= row0[blk + 1]) ++blk;
+      w = src[blk][enc_index(row - row0[blk], col, ld)];
+    }
     const int a = r >> 3, p = (r & 7) >> 1, e = r & 1, b = c >> 2, h = (c & 3) >> 1, f = c & 1;
     dst[(((4 * h + p) * 64) + a + 8 * b) * 4 + 2 * f + e] = w;
   }
+}
+
+// ---- the sweep sharded over P row-block sessions (relax_sharded_engine.h) --------------------------------------
+// Session b sweeps segment b of the tile list (equal tile counts, so equal work) into its own partials; a point's
+// move needs the partials of every segment, so each session folds ITS partials per point (symm_partial_kernel: what
+// symm_apply_kernel sums, restricted to one segment) and stores the result into slot b of the inbox of the session
+// that OWNS the point (its row block: a peer store when that is another GPU) -- npad x DIM floats per session and
+// iteration, whatever the size of the partials; behind the engine's barrier the owner adds the P slots in the
+// order of the sessions (symm_owner_apply_kernel), moves its points and stores them into every session's positions.
+
+// grid: npad / 32 workgroups of 32 parts x 32 points.  inbox[q]: owner q's inbox, [P][npad][DIM]; own0: first row of
+// every owner (n_own + 1 entries); tile-rows [r_first, r_last] hold this segment's tiles (r_first > r_last: none).
+template <int DIM>
+__global__ __launch_bounds__(32 * 32) void symm_partial_kernel(
+    const float* __restrict__ rowpart, const float* __restrict__ colpart, const int2* __restrict__ row_units, int r_first,
+    int r_last, int n, int npad, float* const* __restrict__ inbox, const int* __restrict__ own0, int n_own, int slot,
+    const RunState* st) {
+  if (st != nullptr && st->stopped) return;
+  __shared__ float red[32][kSymCols][DIM];
+  const int R = blockIdx.x >> 1;
+  const int part = threadIdx.x >> 5, pt = threadIdx.x & 31;
+  const int i = blockIdx.x * kSymCols + pt;
+  float acc[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) acc[d] = 0.0f;
+  const int r_stop = R < r_last + 1 ? R : r_last + 1;     // tile-rows of this segment strictly above the point's own
+  for (int Rp = r_first + part; Rp < r_stop; Rp += 32) {
+    const float* src = colpart + ((size_t)(Rp - r_first) * npad + i) * DIM;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) acc[d] += src[d];
+  }
+  if (R >= r_first && R <= r_last) {
+    const int2 ru = row_units[R - r_first];
+    const int row_in_tile = i - R * kSymRows;
+    for (int q = part; q < ru.y; q += 32) {
+      const float* src = rowpart + ((size_t)(ru.x + q) * kSymRows + row_in_tile) * DIM;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) acc[d] -= src[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) red[part][pt][d] = acc[d];
+  __syncthreads();
+  if (part == 0 && i < n) {
+    int q = 0;
+    while (q + 1 < n_own && i >= own0[q + 1]) ++q;
+    float* dst = inbox[q] + ((size_t)slot * npad + i) * DIM;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      float t = red[0][pt][d];
+#pragma unroll
+      for (int p = 1; p < 32; ++p) t += red[p][pt][d];
+      dst[d] = t;
+    }
+  }
+}
+
+// The owner's points [row_begin, row_end): new position = old + the P slots of its inbox in session order; stored into
+// its own next-position buffer and into the other sessions' (push / n_push, as the stage kernel's epilogue does).
+template <int DIM>
+__global__ __launch_bounds__(256) void symm_owner_apply_kernel(
+    const float* __restrict__ pos_in, float* __restrict__ pos_out, const float* __restrict__ inbox, int n_slots, int npad,
+    int row_begin, int row_end, float* const* __restrict__ push, int n_push, int iter1, RunState* st) {
+  if (st != nullptr && st->stopped) return;
+  const int i = row_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row_end) return;
+  bool finite = true;
+  float out[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    float t = 0.0f;
+    for (int b = 0; b < n_slots; ++b) t += inbox[((size_t)b * npad + i) * DIM + d];
+    out[d] = pos_in[(size_t)i * DIM + d] + t;
+    finite = finite && isfinite(out[d]);
+    pos_out[(size_t)i * DIM + d] = out[d];
+  }
+  for (int q = 0; q < n_push; ++q) {
+    float* dst = push[q];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) dst[(size_t)i * DIM + d] = out[d];
+  }
+  if (!finite && st != nullptr) atomicMin(&st->first_nonfinite, iter1);
 }
 
 }  // namespace topolow

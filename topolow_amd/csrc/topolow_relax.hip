@@ -277,6 +277,17 @@ struct topolow_session {
     DevBuf<SymUnit> units;
     DevBuf<int> wave_first;
     DevBuf<int2> row_units;
+    DevBuf<const uint32_t*> src_tab;   // the row blocks the tile-major copy is gathered from (one: the session's own)
+    DevBuf<int> src_row0;
+    // the sweep sharded over the row-block sessions of a run (relax_sharded_engine.h): this session's segment
+    bool seg_ready = false;        // built for the run's current set of sessions
+    bool seg_thr = false;          // some session of the run holds threshold targets: the classifying instance
+    int seg_first = 0, seg_last = -1;   // tile-rows that hold a tile of the segment
+    int seg_slots = 0;             // sessions of the run (slots of an inbox)
+    DevBuf<float> inbox;           // [seg_slots][npad][ndim]: every session's folded partials of this session's points
+    DevBuf<float*> inbox_tab;      // every session's inbox (self included)
+    DevBuf<int> own0;              // first row of every session, then n
+    std::vector<const void*> seg_peers;   // the sessions the segment was built with (their encoded blocks)
   } sym;
   int fused_parts = 0;             // partial sums the last ERR launch wrote (stage kernel: workgroups; sweep: units)
   // profiling (roofline accounting)
@@ -573,6 +584,7 @@ void download_positions(topolow_session* s, const void* src, double* host_colmaj
 
 void compute_row_flags(topolow_session* s) {
   s->sym.ready = false;   // the encoded block changed: the symmetric sweep's copy is rebuilt on first use
+  s->sym.seg_ready = false;
   s->rowflags.alloc(s->rows());
   DevBuf<unsigned long long> measured;
   measured.alloc(1);
@@ -683,15 +695,19 @@ bool sym_eligible(const topolow_session* s) {
          s->dim == s->udim;
 }
 
+// Builds the plan, the tile-major copy and the partial buffers of tiles [t0, t1) of the upper triangle (t1 < 0: all of
+// it) from the row blocks `src` (device pointers of their encoded blocks, first rows in row0[0..n_src]).
 template <int DIM>
-void sym_prepare(topolow_session* s) {
+void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, const std::vector<int>& row0, bool any_thr,
+               long long t0, long long t1) {
   if constexpr (!kSymDim<DIM>) {
     throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
   } else {
     auto& y = s->sym;
     y.npad = (s->n + kSymRows - 1) & ~(kSymRows - 1);
     const int TR = y.npad / kSymRows, TC = y.npad / kSymCols;
-    y.tiles = TR * (TR + 1);
+    if (t1 < 0) t1 = (long long)TR * (TR + 1);
+    y.tiles = (int)(t1 - t0);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int occ = 1 << 30;   // the session's two instances (plain, ERR) share one plan: the smaller occupancy decides the grid
@@ -700,7 +716,7 @@ void sym_prepare(topolow_session* s) {
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * kSymWaves, 0));
       occ = std::min(occ, std::max(1, per_cu));
     };
-    if (s->any_threshold) {
+    if (any_thr) {
       probe(&symm_sweep_kernel<DIM, true, false>);
       probe(&symm_sweep_kernel<DIM, true, true>);
     } else {
@@ -708,21 +724,32 @@ void sym_prepare(topolow_session* s) {
       probe(&symm_sweep_kernel<DIM, false, true>);
     }
     y.grid = occ * prop.multiProcessorCount;
-    const SymPlan plan = relax_symm_plan(y.npad, y.grid * kSymWaves);
+    const SymPlan plan = relax_symm_plan(y.npad, y.grid * kSymWaves, t0, t1, &y.seg_first, &y.seg_last);
     y.n_units = (int)plan.units.size();
-    y.units.alloc(plan.units.size());
+    y.units.alloc(std::max<size_t>(plan.units.size(), 1));
     y.wave_first.alloc(plan.wave_first.size());
-    y.row_units.alloc(plan.row_units.size());
-    HIP_TRY(hipMemcpy(y.units.p, plan.units.data(), plan.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
+    y.row_units.alloc(std::max<size_t>(plan.row_units.size(), 1));
+    if (!plan.units.empty())
+      HIP_TRY(hipMemcpy(y.units.p, plan.units.data(), plan.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(y.wave_first.p, plan.wave_first.data(), plan.wave_first.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(y.row_units.p, plan.row_units.data(), plan.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
-    y.tenc.alloc((size_t)y.tiles * kSymTileWords);
-    hipLaunchKernelGGL(symm_tiles_kernel, dim3(y.tiles), dim3(256), 0, s->stream, s->enc.p, s->rows(), s->ld, y.tenc.p, TC);
+    if (!plan.row_units.empty())
+      HIP_TRY(hipMemcpy(y.row_units.p, plan.row_units.data(), plan.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
+    y.src_tab.alloc(src.size());
+    y.src_row0.alloc(row0.size());
+    HIP_TRY(hipMemcpy(y.src_tab.p, src.data(), src.size() * sizeof(const uint32_t*), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(y.src_row0.p, row0.data(), row0.size() * sizeof(int), hipMemcpyHostToDevice));
+    y.tenc.alloc((size_t)std::max(y.tiles, 1) * kSymTileWords);
+    if (y.tiles > 0)
+      hipLaunchKernelGGL(symm_tiles_kernel, dim3(y.tiles), dim3(256), 0, s->stream, y.src_tab.p, y.src_row0.p, (int)src.size(),
+                         s->ld, y.tenc.p, TC, t0);
     HIP_TRY(hipGetLastError());
     constexpr int W = SymRec<DIM>::W;
     for (auto& r : y.rec) r.alloc((size_t)y.npad * W);
-    y.rowpart.alloc((size_t)y.n_units * kSymRows * DIM);
-    y.colpart.alloc((size_t)TR * y.npad * DIM);
+    const int seg_rows = y.seg_last >= y.seg_first ? y.seg_last - y.seg_first + 1 : 1;
+    y.rowpart.alloc((size_t)std::max(y.n_units, 1) * kSymRows * DIM);
+    y.colpart.alloc((size_t)seg_rows * y.npad * DIM);
+    // (a segment's first and last tile-row are partial: the columns its tiles never reach must read as zero)
+    HIP_TRY(hipMemsetAsync(y.colpart.p, 0, (size_t)seg_rows * y.npad * DIM * sizeof(float), s->stream));
     if ((size_t)y.n_units > s->part_sum.n) {   // error partials: one per unit
       HIP_TRY(hipStreamSynchronize(s->stream));
       HIP_TRY(hipStreamSynchronize(s->check_stream));
@@ -730,8 +757,14 @@ void sym_prepare(topolow_session* s) {
       s->part_cnt.alloc(y.n_units);
     }
     y.rec_iter = -1;
-    y.ready = true;
   }
+}
+
+template <int DIM>
+void sym_prepare(topolow_session* s) {
+  sym_build<DIM>(s, {s->enc.p}, {0, s->rows()}, s->any_threshold, 0, -1);
+  s->sym.ready = true;
+  s->sym.seg_ready = false;
 }
 
 // Builds the sweep's buffers on first use.  They cost device memory (half the encoded block again, plus the
@@ -773,7 +806,7 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
     auto sweep = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec, y.units.p, y.wave_first.p,
                          y.rowpart.p, y.colpart.p, y.npad, s->state.p, s->part_sum.p, s->part_cnt.p,
-                         s->block_cells);
+                         s->block_cells, 0);
     };
     if (s->any_threshold) {
       if (err) sweep(&symm_sweep_kernel<DIM, true, true>); else sweep(&symm_sweep_kernel<DIM, true, false>);
@@ -789,6 +822,131 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
     y.rec_iter = iter + 1;
     if (err) s->fused_parts = y.n_units;
     s->stage_launches += 1;
+  }
+}
+
+// ---- the symmetric sweep sharded over the row-block sessions of one run (relax_symm.h, relax_sharded_engine.h) ----
+bool sym_sharded_eligible(const std::vector<topolow_session*>& ss) {
+  const char* e = getenv("TOPOLOW_SHARD_SYMMETRIC");
+  if (e != nullptr && e[0] == '0') return false;       // row-owner sweeps only
+  const int P = (int)ss.size();
+  if (P < 2) return false;
+  const topolow_session* a = ss[0];
+  const long long TR = ((a->n + kSymRows - 1) & ~(kSymRows - 1)) / kSymRows;
+  if (TR * (TR + 1) < 8ll * P) return false;
+  for (const topolow_session* s : ss)
+    if (!(s->sym.allowed && s->schedule == TOPOLOW_SCHEDULE_SLAB && s->precision == TOPOLOW_PRECISION_F32 && s->dim >= 2 &&
+          s->dim <= 6 && s->dim == s->udim && s->n >= s->sym.min_n && s->rows() > 0 && s->fuse_checks == a->fuse_checks))
+      return false;
+  return true;
+}
+
+// Session b's segment: tiles [total b / P, total (b + 1) / P) of the tile-row-major list, gathered from every session's
+// row block (peer reads where the sessions sit on different GPUs).  Kept while the same sessions run together again.
+template <int DIM>
+void sym_sharded_build(std::vector<topolow_session*>& ss, int b) {
+  const int P = (int)ss.size();
+  topolow_session* s = ss[b];
+  std::vector<const uint32_t*> src;
+  std::vector<const void*> peers;
+  std::vector<int> row0;
+  bool any_thr = false;
+  for (topolow_session* q : ss) {
+    src.push_back(q->enc.p);
+    peers.push_back(q->enc.p);
+    row0.push_back(q->row_begin);
+    any_thr = any_thr || q->any_threshold;
+  }
+  row0.push_back(s->n);
+  auto& y = s->sym;
+  if (y.seg_ready && y.seg_peers == peers && y.seg_thr == any_thr) return;
+  HIP_TRY(hipSetDevice(s->device));
+  const long long npad = (s->n + kSymRows - 1) & ~(kSymRows - 1);
+  const long long TR = npad / kSymRows, total = TR * (TR + 1);
+  sym_build<DIM>(s, src, row0, any_thr, total * b / P, total * (b + 1) / P);
+  if (y.seg_first < 0) { y.seg_first = 0; y.seg_last = -1; }
+  y.ready = false;            // the buffers now describe a segment, not the session's own whole-matrix plan
+  y.seg_thr = any_thr;
+  y.seg_slots = P;
+  y.inbox.alloc((size_t)P * y.npad * DIM);
+  HIP_TRY(hipMemsetAsync(y.inbox.p, 0, (size_t)P * y.npad * DIM * sizeof(float), s->stream));
+  y.own0.alloc(row0.size());
+  HIP_TRY(hipMemcpy(y.own0.p, row0.data(), row0.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  y.seg_peers = peers;
+}
+
+void sym_sharded_prepare(std::vector<topolow_session*>& ss) {
+  const int P = (int)ss.size();
+  for (topolow_session* s : ss) {   // every block is loaded before anybody gathers from it
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  for (int b = 0; b < P; ++b) TL_DISPATCH_DIM(ss[b]->dim, sym_sharded_build, ss, b);
+  for (int b = 0; b < P; ++b) {
+    topolow_session* s = ss[b];
+    HIP_TRY(hipSetDevice(s->device));
+    // a segment meets points of every row block: their degree terms come from the owners (a caller that fills a
+    // block in place -- topolow_session_commit_encoded -- need only know its own rows' degrees)
+    for (topolow_session* q : ss)
+      if (q != s && q->rows() > 0)
+        HIP_TRY(hipMemcpy(s->gplus.p + q->row_begin, q->gplus.p + q->row_begin, (size_t)q->rows() * sizeof(float),
+                          hipMemcpyDeviceToDevice));
+    std::vector<float*> tab;
+    for (topolow_session* q : ss) tab.push_back(q->sym.inbox.p);
+    s->sym.inbox_tab.alloc(P);
+    HIP_TRY(hipMemcpy(s->sym.inbox_tab.p, tab.data(), P * sizeof(float*), hipMemcpyHostToDevice));
+    s->sym.seg_ready = true;
+  }
+}
+
+// First half of a one-stage iteration of session s: records of all points from `pin`, the sweep of its segment, its
+// partials folded per point into slot `rank` of the owners' inboxes.  err: the sweep also reduces its pairs' share of
+// the pending check's MAE (one partial per unit: s->fused_parts).
+template <int DIM>
+void sym_sharded_sweep(topolow_session* s, const void* pin, int iter, double k, bool err) {
+  if constexpr (!kSymDim<DIM>) {
+    throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
+  } else {
+    auto& y = s->sym;
+    ProfScope prof(s, err ? &s->prof_sym_err : &s->prof_sym);
+    const int TC = y.npad / kSymCols;
+    hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((y.npad + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
+                       s->gplus.p, y.rec[0].p, s->n, y.npad, k, s->c_rep);
+    auto sweep = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, y.rec[0].p, y.units.p,
+                         y.wave_first.p, y.rowpart.p, y.colpart.p, y.npad, s->state.p, s->part_sum.p, s->part_cnt.p,
+                         s->block_cells, y.seg_first);
+    };
+    if (y.tiles > 0) {
+      if (y.seg_thr) {
+        if (err) sweep(&symm_sweep_kernel<DIM, true, true>); else sweep(&symm_sweep_kernel<DIM, true, false>);
+      } else {
+        if (err) sweep(&symm_sweep_kernel<DIM, false, true>); else sweep(&symm_sweep_kernel<DIM, false, false>);
+      }
+    }
+    hipLaunchKernelGGL(symm_partial_kernel<DIM>, dim3(TC), dim3(32 * 32), 0, s->stream, y.rowpart.p, y.colpart.p,
+                       y.row_units.p, y.seg_first, y.seg_last, s->n, y.npad, y.inbox_tab.p, y.own0.p, y.seg_slots, s->rank,
+                       s->state.p);
+    HIP_TRY(hipGetLastError());
+    if (err) s->fused_parts = y.n_units;
+    (void)iter;
+    s->stage_launches += 1;
+  }
+}
+
+// Second half, behind the run's barrier: the session's own points move by the sum of the inbox's slots; `push`: the
+// other sessions' copies of the output buffer.
+template <int DIM>
+void sym_sharded_apply(topolow_session* s, const void* pin, void* pout, const void* push, int iter) {
+  if constexpr (!kSymDim<DIM>) {
+    throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
+  } else {
+    auto& y = s->sym;
+    hipLaunchKernelGGL(symm_owner_apply_kernel<DIM>, dim3((s->rows() + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
+                       (float*)pout, y.inbox.p, y.seg_slots, y.npad, s->row_begin, s->row_end, (float* const*)push, s->n_push,
+                       iter + 1, s->state.p);
+    HIP_TRY(hipGetLastError());
   }
 }
 
@@ -1925,6 +2083,23 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
     }
     if (expect != n) throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "row-sharded run: the row blocks do not cover all n rows"};
     sharded_wire(R.ss);
+    if (sym_sharded_eligible(R.ss)) {
+      // one-stage iterations as the symmetric sweep sharded over the sessions; a device that cannot hold the extra
+      // buffers (half a row block again per session) keeps the row-owner sweep
+      try {
+        sym_sharded_prepare(R.ss);
+        R.pair_sharded = true;
+      } catch (const HipError&) {
+        (void)hipGetLastError();
+        for (topolow_session* s : R.ss) {
+          auto& y = s->sym;
+          y.tenc.release(); y.rec[0].release(); y.rec[1].release(); y.rowpart.release(); y.colpart.release();
+          y.units.release(); y.wave_first.release(); y.row_units.release(); y.inbox.release();
+          y.ready = false; y.seg_ready = false;
+        }
+        R.pair_sharded = false;
+      }
+    }
     // groups: blocks that share a GPU share one stream and one host thread
     const char* per_block = getenv("TOPOLOW_SHARD_THREAD_PER_BLOCK");
     const bool thread_per_block = per_block != nullptr && per_block[0] == '1';
