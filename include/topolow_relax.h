@@ -413,7 +413,8 @@ typedef struct topolow_shard_stats {
   /* Measurement aid, IN and out (topolow_sessions_run_sharded only): when > 0 on entry, the GPUs are
    * drained once these iterations have run and `timed_seconds` covers the rest of the loop -- the
    * steady state without the 16-stage iterations of the unfolding phase. */
-  int32_t warmup_iterations, reserved1;
+  int32_t warmup_iterations;
+  int32_t symmetric_segments;    /* > 0: one-stage iterations ran as the symmetric sweep sharded over this many sessions */
   double timed_seconds;
   int64_t reserved[2];
 } topolow_shard_stats;

@@ -228,12 +228,15 @@ def test_sharded_symmetric_sweep_equals_the_single_block(dim, thr, thread_per_bl
         assert np.allclose(tr[:, 1], t_one[:, 1], rtol=2e-6, atol=0), (blocks, tr[:, 1], t_one[:, 1])
         assert got.iterations == one.iterations and got.final_mae == pytest.approx(one.final_mae, rel=2e-6)
         assert got.info["groups"] == (blocks if thread_per_block == "1" else 1)
+        assert got.info["symmetric_segments"] == blocks                  # the sharded sweep really ran
+    assert one.info["symmetric_segments"] == 0
     # ... and the sharded sweep against the row-owner engine (TOPOLOW_SHARD_SYMMETRIC=0): same band
     monkeypatch.setenv("TOPOLOW_SHARD_SYMMETRIC", "0")
     ss = _sessions(call, n, dim, 2, env)
     ro = _native.run_sharded(ss, call.initial_positions, iters, 1.5, 0.01, 0.01, 1e-12, 10 ** 9, 3, 5, 1)
     for s in ss:
         s.close()
+    assert ro.info["symmetric_segments"] == 0
     assert np.abs(ro.positions - runs[2][0].positions).max() <= 2e-5 * scale * iters
 
 

@@ -58,7 +58,7 @@ class TopolowShardStats(C.Structure):
                 ("groups", C.c_int32), ("loop_seconds", C.c_double), ("total_seconds", C.c_double),
                 ("stage_kernel_seconds", C.c_double), ("check_kernel_seconds", C.c_double),
                 ("stage_launches", C.c_int64), ("exchanges", C.c_int64), ("warmup_iterations", C.c_int32),
-                ("reserved1", C.c_int32), ("timed_seconds", C.c_double), ("reserved", C.c_int64 * 2)]
+                ("symmetric_segments", C.c_int32), ("timed_seconds", C.c_double), ("reserved", C.c_int64 * 2)]
 
 
 class TopolowProblem(C.Structure):
@@ -604,7 +604,8 @@ def run_sharded(sessions, initial_positions, n_iter, k0, cooling_rate, c_repulsi
     info = dict(schedule="slab", blocks=stats.blocks, groups=stats.groups, iterations_run=stats.iterations_run,
                 n_checks=stats.n_checks, loop_seconds=stats.loop_seconds, stage_kernel_seconds=stats.stage_kernel_seconds,
                 check_kernel_seconds=stats.check_kernel_seconds, stage_launches=stats.stage_launches,
-                exchanges=stats.exchanges, timed_seconds=stats.timed_seconds)
+                exchanges=stats.exchanges, timed_seconds=stats.timed_seconds,
+                symmetric_segments=stats.symmetric_segments)
     return NativeResult(np.ascontiguousarray(out), bool(conv.value), int(iters.value), float(fmae.value),
                         float(fk.value), info)
 

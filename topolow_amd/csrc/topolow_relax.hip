@@ -2202,6 +2202,7 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
         stats->stage_launches = s0->stage_launches - launches0;
         stats->exchanges = R.exchanges;
         stats->warmup_iterations = warmup_iters;
+        stats->symmetric_segments = R.pair_sharded ? count : 0;
         stats->timed_seconds = (warmup_iters > 0 && R.t_timed0 > 0.0) ? (t0 + wall) - R.t_timed0 : wall;
         if (profile) {
           for (int b : R.groups[0].blocks) {
