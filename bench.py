@@ -110,7 +110,7 @@ def run_single(args):
     n_job = int(iters_run)
 
     # ---- timed region: the job in slices of EXACTLY K iterations.  The schedule's cost per iteration is not
-    # uniform (16 stages per iteration while the layout unfolds, two while k > 2.5, then one: DESIGN.md section
+    # uniform (16 stages per iteration while the layout unfolds, two while k > 3, then one: DESIGN.md section
     # 2b), so K iterations from one place would price that place, not the job; every iteration of the job is
     # therefore timed exactly once per rotation, K at a time, each slice bracketed by device synchronisations,
     # and value = K / mean slice.  The W warm-up iterations are spent before the job starts.  (Throughput run: the controller checks and
@@ -212,7 +212,7 @@ def run_single(args):
         "stage_kernel": priced(stage_ms - fused_ms, plain_launches, bytes_iter * (n_timed - sym_iters - sym_err_iters
                                                                                   - fused_launches),
                                "slab_stage_pipe_kernel<5,float>",
-                               "row-owner launches: 1/16 of the columns while the layout unfolds, 1/2 while k > 2.5 "
+                               "row-owner launches: 1/16 of the columns while the layout unfolds, 1/2 while k > 3 "
                                "(and whole-matrix ones where the symmetric sweep does not apply)"),
         "stage_kernel_with_check": priced(fused_ms, fused_launches, bytes_iter * fused_launches,
                                           "slab_stage_pipe_kernel<5,float,...,ERR=true>", "row-owner whole-matrix "

@@ -170,10 +170,10 @@ PROBLEMS = {
                                  doc="cfg3_generator(1500, eps=1e-6)"),
     "cfg3gen_1500_eps1e-10": dict(fn=functools.partial(_cfg3gen, 1500, 0.0, 1e-10),
                                   doc="cfg3_generator(1500, eps=1e-10)"),
-    # a soft, slowly cooling spring: after the unfolding phase every iteration is ONE Jacobi sweep (k <= 2.5)
+    # a soft, slowly cooling spring: after the unfolding phase every iteration is ONE Jacobi sweep (k <= 3)
     "cfg3gen_1500_lowk": dict(fn=functools.partial(_cfg3gen, 1500, 0.0, 1e-4, k0=2.0, cool=0.004, c_rep=0.01),
                               doc="cfg3_generator(1500, k0=2.0, cool=0.004)"),
-    # low dimensions: the stage policy is k / S <= min(2.5, ndim) (a Jacobi stage is stable for k / S < 2 ndim)
+    # low dimensions: the stage policy is k / S <= min(3, ndim) (a Jacobi stage is stable for k / S < 2 ndim)
     "syn1500_ndim2": dict(fn=lambda: _syn_lowdim(1500, 2, 0.7, 11), doc="random_problem(1500, 2, 0.7, seed=11, "
                           "n_iter=1000, k0=5, cool=0.01, c_rep=0.01)"),
     "syn2000_ndim3_sparse": dict(fn=lambda: _syn_lowdim(2000, 3, 0.9, 12), doc="random_problem(2000, 3, 0.9, seed=12, "

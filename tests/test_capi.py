@@ -67,14 +67,15 @@ def test_slab_plan_covers_every_column_once(n, stages):
 
 
 def test_slab_stage_policy():
-    # k / stages <= min(2.5, ndim): one sweep per iteration once k <= 2.5 (ndim >= 3)
-    assert _native.slab_stages_for_k(0.1, 5) == 1 and _native.slab_stages_for_k(2.5, 5) == 1
-    assert _native.slab_stages_for_k(5.0, 5) == 2 and _native.slab_stages_for_k(10.0, 3) == 4
+    # k / stages <= min(3, ndim): one sweep per iteration once k <= 3 (ndim >= 3)
+    assert _native.slab_stages_for_k(0.1, 5) == 1 and _native.slab_stages_for_k(3.0, 5) == 1
+    assert _native.slab_stages_for_k(3.01, 5) == 2 and _native.slab_stages_for_k(5.0, 5) == 2
+    assert _native.slab_stages_for_k(10.0, 3) == 4
     assert _native.slab_stages_for_k(14.76, 5) == 8 and _native.slab_stages_for_k(30.0, 5) == 16
     assert _native.slab_stages_for_k(5.0, 1) == 8 and _native.slab_stages_for_k(5.0, 2) == 4     # stability: k / S < 2 ndim
-    # while the layout unfolds (first 16 iterations) never fewer than 16 stages
-    assert _native.slab_stages_at(0, 5.0, 5) == 16 and _native.slab_stages_at(15, 5.0, 5) == 16
-    assert _native.slab_stages_at(16, 5.0, 5) == 2 and _native.slab_stages_at(3, 100.0, 5) == 64
+    # while the layout unfolds (first 8 iterations) never fewer than 16 stages
+    assert _native.slab_stages_at(0, 5.0, 5) == 16 and _native.slab_stages_at(7, 5.0, 5) == 16
+    assert _native.slab_stages_at(8, 5.0, 5) == 2 and _native.slab_stages_at(3, 100.0, 5) == 64
 
 
 @pytest.mark.parametrize("n", [2, 3, 5, 8, 33, 64, 101])

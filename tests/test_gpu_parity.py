@@ -234,7 +234,7 @@ def test_checks_beside_next_iteration_change_nothing(monkeypatch):
 
 
 def test_check_fused_into_the_next_iterations_sweep(monkeypatch):
-    """Once k <= 2.5 an iteration is ONE stage, and that stage meets every pair from the positions the previous
+    """Once k <= 3 an iteration is ONE stage, and that stage meets every pair from the positions the previous
     iteration left -- the positions the previous iteration's convergence check measures.  The kernel then reduces
     the check's MAE on its way (ERR launch) and the separate pass over the block is dropped;
     TOPOLOW_FUSE_CHECKS=0 keeps the separate pass.  Same trajectory and verdicts; the MAE agrees to fp32 rounding

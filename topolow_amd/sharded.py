@@ -599,7 +599,7 @@ def _bench_sharded_native(args, devices):
     init[1:] = np.cumsum(rng.uniform(0.0, 2.0 * scale / n, size=(n - 1, ndim)), axis=0)
     ss = [bk.session for bk in backs]
     sync = lambda: [torch.cuda.synchronize(d) for d in sorted(set(devices))]
-    W = max(W, 16)     # the unfolding phase (16 iterations of 16 stages) belongs to the warm-up
+    W = max(W, 16)     # the unfolding phase (8 iterations of 16 stages) belongs to the warm-up
     _native.run_sharded(ss, init, 3, k0, cool, c_rep, 1e-4, 10 ** 9, 3, 7, args.stages)
     sync()
     passes = []
