@@ -183,4 +183,28 @@ def test_symmetric_sweep_instances_fit_their_register_budget():
         assert re.search(r"; ScratchSize: (\d+)", tail).group(1) == "0", name
         assert int(re.search(r"; Occupancy: (\d+)", tail).group(1)) >= 2, name
         body = text[start:end]
-        assert body.count("v_add_f32_dpp") % (3 * 2 * int(dim)) == 0 and "v_add_f32_dpp" in body, name
+        # three DPP steps on ndim values per half tile (csrc/relax_symm.h: sym_col_reduce)
+        assert body.count("v_add_f32_dpp") % (3 * int(dim)) == 0 and "v_add_f32_dpp" in body, name
+        # DPP hazard: a VGPR written by a vector instruction may be read through DPP only two wait states later; the
+        # adds are inline asm, so the compiler neither knows nor pads -- no instruction among the two before a DPP add
+        # may write the register it reads through DPP (an s_nop counts as wait states)
+        lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        for k, ln in enumerate(lines):
+            m = re.match(r"v_add_f32_dpp v\d+, v(\d+), v\d+", ln)
+            if not m:
+                continue
+            src = int(m.group(1))
+            waits = 0
+            for prev in reversed(lines[max(0, k - 4):k]):
+                if waits >= 2:
+                    break
+                nop = re.match(r"s_nop (\d+)", prev)
+                if nop:
+                    waits += int(nop.group(1)) + 1
+                    continue
+                w = re.match(r"v_\w+ v(\d+)|v_\w+ v\[(\d+):(\d+)\]", prev)
+                if w:
+                    lo = int(w.group(1) or w.group(2))
+                    hi = int(w.group(1) or w.group(3))
+                    assert not (lo <= src <= hi), (name, prev, ln)
+                waits += 1

@@ -16,7 +16,8 @@ minutes each).  Further bands, stated where they are asserted:
     largest deviation seen in the 32-seed studies is 8.3 %; the sparse 3-D problem's own oracle spread is 9 %);
   * recovered distances: a run's distances among the first 48 points differ from the oracle's seed-mean
     by no more than 1.5 x the largest gap an oracle seed shows + 0.5 %;
-  * spread: sd of the device's final MAEs <= 2 sd_ref + 1 % of the mean (check_runs says what is behind it).
+  * spread: robust sd of the device's final MAEs <= 2 sd_ref + 0.5 % of the mean, at most 15 % of the runs further than
+    max(4 sd_ref, 3 %) from the oracle's mean (check_runs says what is behind it).
 Measured means behind these tests: tests/study/gpu_contract_study.py, DESIGN.md section 2.
 """
 import numpy as np
@@ -57,13 +58,18 @@ def check_runs(name, runs, mean_band=None, schedule=None):
     band = contract_band(ref) if mean_band is None else mean_band
     assert abs(got.mean() - m) <= band, (name, schedule, got.mean(), m, band)
     assert np.all(np.abs(got - m) <= max(0.12 * m, 4.0 * ref["sd_final_mae"])), (name, schedule, got.min(), got.max(), m)
-    # spread: the device's run-to-run sd against the oracle's.  The slab schedule is a different random process from
-    # the sequential order: on the config-3 family (k0 = 5, cooling 0.01) it reaches the same bulk of final errors and,
-    # in 5-12 % of the runs, basins the oracle's 20 seeds did not show -- lower ones as well as higher ones (64 device
-    # seeds per problem: profiles/r03_contract_study.txt; config 3: [0.277, 0.303] against the oracle's [0.285, 0.298],
-    # mean +0.2 %) -- which makes its sd 1.6-1.8 x the oracle's there (3.3 x at N = 2048, where 5 of 64 runs end 4-8 %
-    # high), 0.9-1.1 x on the other pinned problems.  Stated band: sd_device <= 2 sd_ref + 1 % of the mean.
-    assert got.std(ddof=1) <= 2.0 * ref["sd_final_mae"] + 0.01 * m, (name, schedule, got.std(ddof=1), ref["sd_final_mae"])
+    # spread: the device's run-to-run scatter against the oracle's.  The slab schedule is a different random process
+    # from the sequential order: on the config-3 family (k0 = 5, cooling 0.01) it reaches the same bulk of final errors
+    # and, in 5-12 % of the runs, basins the oracle's 20 seeds did not show -- lower ones as well as higher ones (64
+    # device seeds per problem: profiles/r03_contract_study.txt; config 3: [0.277, 0.303] against the oracle's
+    # [0.285, 0.298], mean +0.2 %; N = 2048: 59 of 64 runs inside the oracle's range, five 4-8 % high) -- which makes
+    # its plain sd 1.6-1.8 x the oracle's there (3.3 x at N = 2048), 0.9-1.1 x on the other pinned problems.  Stated
+    # bands: the BULK -- robust sd, 1.4826 x the median absolute deviation -- within 2 sd_ref + 0.5 % of the mean, and at
+    # most 15 % of the runs further than max(4 sd_ref, 3 %) from the oracle's mean.
+    bulk = 1.4826 * float(np.median(np.abs(got - np.median(got))))
+    assert bulk <= 2.0 * ref["sd_final_mae"] + 0.005 * m, (name, schedule, bulk, ref["sd_final_mae"])
+    far = float(np.mean(np.abs(got - m) > max(4.0 * ref["sd_final_mae"], 0.03 * m)))
+    assert far <= 0.15, (name, schedule, far, np.sort(got))
     assert abs(its.mean() - ref["mean_iterations"]) <= max(3.0 * ref["sd_iterations"],
                                                             ITER_BAND.get(name, 0.10) * ref["mean_iterations"])
     assert all(r.converged for r in runs) == all(x["converged"] for x in ref["runs"])

@@ -30,11 +30,11 @@ for f in glob.glob(prefix + "_kt/*/*_kernel_trace.csv"):
         small = [x for x in v if x < 20000]
         half = [x for x in v if 20000 <= x < 52000]
         mean = lambda xs: (sum(xs) / len(xs) / 1e3) if xs else None
-        # one job of config 3 (396 iterations: 16 x 16 stages, 53 x 2, 327 x 1 of which 109 carry a check) launches the
-        # plain instance 256 + 106 + 218 times: the mean over THAT mix is what bench.py's roofline.avg_launch_us prices
+        # the trace covers whole rotations of the job, so the mean over ALL launches of the plain instance is the mean over
+        # the job's mix of sixteen-, two- and one-stage launches: what bench.py's by_kind.stage_kernel.avg_launch_us prices
         job_mix = None
-        if small and half and full and k.rstrip(">").endswith("false, false"):
-            job_mix = (256 * mean(small) + 106 * mean(half) + 218 * mean(full)) / 580.0
+        if small and half and k.rstrip(">").endswith("false, false"):
+            job_mix = sum(v) / len(v) / 1e3
         out[k] = dict(launches=len(v), mean_us=sum(v) / len(v) / 1e3, sixteen_stage_launches=len(small),
                       sixteen_stage_mean_us=mean(small), two_stage_launches=len(half), two_stage_mean_us=mean(half),
                       job_mix_mean_us=job_mix,

@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
   uint32_t* d_tenc;
   CK(hipMalloc(&d_tenc, tenc.size() * 4)); CK(hipMemcpy(d_tenc, tenc.data(), tenc.size() * 4, hipMemcpyHostToDevice));
   uint32_t* d_enc; float *d_pos, *d_g, *d_rec, *d_rec2, *d_out, *d_ref, *d_rowp, *d_colp; double *d_err, *d_psum; unsigned long long* d_pcnt;
-  SymUnit* d_units; int2* d_ru; int* d_wf;
+  SymUnit* d_units; int2* d_ru; SymRun* d_wf;
   CK(hipMalloc(&d_enc, enc.size() * 4)); CK(hipMemcpy(d_enc, enc.data(), enc.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_pos, pos.size() * 4)); CK(hipMemcpy(d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_g, n * 4)); CK(hipMemcpy(d_g, g.data(), n * 4, hipMemcpyHostToDevice));
@@ -101,7 +101,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_err, n * 8)); CK(hipMalloc(&d_psum, n_units * 8)); CK(hipMalloc(&d_pcnt, n_units * 8));
   CK(hipMalloc(&d_units, n_units * sizeof(SymUnit))); CK(hipMemcpy(d_units, units.data(), n_units * sizeof(SymUnit), hipMemcpyHostToDevice));
   CK(hipMalloc(&d_ru, TR * sizeof(int2))); CK(hipMemcpy(d_ru, row_units.data(), TR * sizeof(int2), hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_wf, plan.wave_first.size() * 4)); CK(hipMemcpy(d_wf, plan.wave_first.data(), plan.wave_first.size() * 4, hipMemcpyHostToDevice));
+  const std::vector<SymRun> runs = plan.runs();
+  CK(hipMalloc(&d_wf, runs.size() * sizeof(SymRun))); CK(hipMemcpy(d_wf, runs.data(), runs.size() * sizeof(SymRun), hipMemcpyHostToDevice));
 
   hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((npad + 255) / 256), dim3(256), 0, 0, d_pos, d_g, d_rec, n, npad, k, c_rep);
   hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((npad + 255) / 256), dim3(256), 0, 0, d_pos, d_g, d_rec2, n, npad, k, c_rep);

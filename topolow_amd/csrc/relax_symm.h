@@ -51,22 +51,38 @@ struct SymUnit {
 // diagonal): with TC = npad / 32 column blocks, tile (R, J), J >= 2 R, is 8 KB at tile index R TC - R (R - 1) + (J - 2 R),
 // so a unit is one contiguous run.  Inside a tile a lane's eight 16-byte loads are the (column half h, row pair p)
 // groups in the order the sweep consumes them: the words of rows 8a + 2p + {0, 1} x columns 4b + 2h + {0, 1} sit at
-// (((4 h + p) * 64 + a + 8 b) * 4 + 2 f + e) -- a column's two rows adjacent, as the packed pair update reads them;
-// each load of the wave covers 1 KB.
+// (((4 h + p) * 64 + a + 8 b) * 4 + 2 (f ^ (a & 1)) + e) -- a column's two rows adjacent, as the packed pair update
+// reads them, and the two columns of a half in opposite order for odd and even a: a lane sweeps "its first" column
+// then "its second", which for odd a are columns 2h + 1 and 2h, so that the first step of the column reduction --
+// between the lanes a and a ^ 1 -- can add the one's first to the other's second with one instruction per
+// coordinate (sym_col_reduce).  Each load of the wave covers 1 KB.
 inline long long sym_tile_index(int R, int J, int TC) { return (long long)R * TC - (long long)R * (R - 1) + (J - 2 * R); }
 inline size_t sym_word_in_tile(int r, int c) {   // r in [0, 64), c in [0, 32)
   const int a = r >> 3, p = (r & 7) >> 1, e = r & 1, b = c >> 2, h = (c & 3) >> 1, f = c & 1;
-  return (size_t)((((4 * h + p) * 64) + a + 8 * b) * 4 + 2 * f + e);
+  return (size_t)((((4 * h + p) * 64) + a + 8 * b) * 4 + 2 * (f ^ (a & 1)) + e);
 }
 
 // Host: the plan of a sweep over npad / 64 tile-rows for a grid of n_waves waves.
 //   units      : tile-row-major; unit u covers column blocks [j0, j1) of tile-row R
-//   wave_first : n_waves + 1 entries, wave w sweeps units [wave_first[w], wave_first[w + 1])
+//   wave_first : n_waves + 1 entries, wave w sweeps units [wave_first[w], wave_first[w + 1]) (the kernel reads runs())
 //   row_units  : per tile-row (first unit, number of units)
+struct SymRun {      // one wave's run: units [u0, u1), the first of them inline (one load instead of two dependent ones)
+  int u0, u1;
+  SymUnit first;
+};
 struct SymPlan {
   std::vector<SymUnit> units;
   std::vector<int> wave_first;
   std::vector<int2> row_units;
+  std::vector<SymRun> runs() const {       // what the kernel reads: wave_first with every wave's first unit beside it
+    std::vector<SymRun> r(wave_first.size() - 1);
+    for (size_t w = 0; w + 1 < wave_first.size(); ++w) {
+      r[w].u0 = wave_first[w];
+      r[w].u1 = wave_first[w + 1];
+      r[w].first = r[w].u0 < r[w].u1 ? units[r[w].u0] : SymUnit{0, 0, 0, 0};
+    }
+    return r;
+  }
 };
 // The plan of the tiles [t0, t1) of the tile-row-major list (a SEGMENT: the whole list on one GPU, one of P equal
 // runs of it when the sweep is sharded over P row-block sessions): tile0 counts from t0, row_units is indexed by
@@ -123,16 +139,28 @@ __device__ unsigned long long* g_sym_stamps = nullptr;   // [4 * waves]: shader 
 // through DPP only two wait states later; sym_col_reduce orders the adds so that a value's next step comes at least
 // two instructions after its previous one, and starts with an s_nop.
 #define TL_SYM_DPP_ADD(v, ctrl) asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
+// Column sums of a half tile over the 8 lanes a = 0..7 of a column group.  In: per lane the sums of ITS first and
+// ITS second column (for even a columns 2h, 2h + 1, for odd a the other way round).  Step 1 (lanes a, a ^ 1): own
+// first + the partner's second -- the same column in both -- so NV adds serve both columns; steps 2 and 3 (a ^ 2, then
+// a + 4 through row_shl:4, which is right for a < 4) on NV values.  Out: first[] holds the total of column 2h in lane
+// a = 0 and of column 2h + 1 in lane a = 1 (round 2 reduced both columns in every lane: 3 x 2 NV adds).
 template <int NV>
-__device__ __forceinline__ void sym_col_reduce(float (&v)[NV]) {
-  static_assert(NV >= 3, "DPP hazard spacing");
+__device__ __forceinline__ void sym_col_reduce(float (&first)[NV], float (&second)[NV]) {
+  // every operand is pinned in its register BEFORE the first DPP read: the empty statements make the compiler finish
+  // the sums that feed them here (left free it sinks one of them between two of the adds below, whose DPP read of the
+  // register just written then returns the old value -- the hazard is invisible to it inside inline asm)
+#pragma unroll
+  for (int q = 0; q < NV; ++q) asm volatile("" : "+v"(first[q]), "+v"(second[q]));
   asm volatile("s_nop 1");
 #pragma unroll
-  for (int q = 0; q < NV; ++q) TL_SYM_DPP_ADD(v[q], "quad_perm:[1,0,3,2]");
+  for (int q = 0; q < NV; ++q)
+    asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(first[q]) : "v"(second[q]));
+  if constexpr (NV < 3) asm volatile("s_nop 1");
 #pragma unroll
-  for (int q = 0; q < NV; ++q) TL_SYM_DPP_ADD(v[q], "quad_perm:[2,3,0,1]");
+  for (int q = 0; q < NV; ++q) TL_SYM_DPP_ADD(first[q], "quad_perm:[2,3,0,1]");
+  if constexpr (NV < 3) asm volatile("s_nop 1");
 #pragma unroll
-  for (int q = 0; q < NV; ++q) TL_SYM_DPP_ADD(v[q], "row_half_mirror");
+  for (int q = 0; q < NV; ++q) TL_SYM_DPP_ADD(first[q], "row_shl:4");
 }
 
 // rows (i0, i1) packed x one column c: both halves of both pairs.  The pair's shared factor is selected ONCE --
@@ -208,7 +236,7 @@ __device__ __forceinline__ void sym_pair(const float (&pc)[DIM], float ksc, floa
 template <int DIM, bool ANYTHR, bool ERR>
 __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_kernel(
     const uint32_t* __restrict__ enc, const float* __restrict__ rec, const SymUnit* __restrict__ units,
-    const int* __restrict__ wave_first, float* __restrict__ rowpart, float* __restrict__ colpart, int npad,
+    const SymRun* __restrict__ runs, float* __restrict__ rowpart, float* __restrict__ colpart, int npad,
     const RunState* st, double* __restrict__ part_sum, unsigned long long* __restrict__ part_cnt,
     unsigned long long fixed_cnt, int col_row0) {
   if (st != nullptr && st->stopped) return;
@@ -227,14 +255,16 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int a = lane & 7, b = lane >> 3;
 
-  // units are dealt statically: wave w of the grid sweeps units [wave_first[w], wave_first[w + 1]) -- the host
+  // units are dealt statically: wave w of the grid sweeps units [runs[w].u0, runs[w].u1) -- the host
   // cuts the tile-row-major list of upper-triangle tiles into equal runs, one per wave (relax_symm_plan)
   const int gw = blockIdx.x * kSymWaves + wave;
-  const int u_end = __builtin_amdgcn_readfirstlane(wave_first[gw + 1]);
+  const SymRun run = runs[gw];
+  const int u_begin = __builtin_amdgcn_readfirstlane(run.u0);
+  const int u_end = __builtin_amdgcn_readfirstlane(run.u1);
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rec), 0, npad * W * 4, 0x00020000);
-  for (int u = __builtin_amdgcn_readfirstlane(wave_first[gw]); u < u_end; ++u) {
-    const SymUnit U = units[u];
+  for (int u = u_begin; u < u_end; ++u) {
+    const SymUnit U = u == u_begin ? run.first : units[u];
     const int R = __builtin_amdgcn_readfirstlane(U.tile_row);
     const int J0 = __builtin_amdgcn_readfirstlane(U.j0), J1 = __builtin_amdgcn_readfirstlane(U.j1);
     const int slot = u;
@@ -269,9 +299,11 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
     // the unit's tiles as one buffer (wave-uniform descriptor): tile J at (J - J0) * 8 KB; a lane's load (h, p) 1 KB apart
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(enc) + (size_t)tile0 * kSymTileWords, 0, (J1 - J0) * kSymTileWords * 4, 0x00020000);
-    // the tile-row's column partials as one buffer; lanes a != 0 get an offset past its end
+    // the tile-row's column partials as one buffer; lane a = 0 stores the first column of a half, a = 1 the second,
+    // the other lanes get an offset past its end
     const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(colpart + (size_t)(R - col_row0) * npad * DIM, 0, npad * DIM * 4, 0x00020000);
-    const int col_off = a == 0 ? 4 * b * DIM * 4 : 0x40000000;
+    const int col_off = a < 2 ? (4 * b + a) * DIM * 4 : 0x40000000;
+    const int swap = a & 1;                // this lane's q-th column of a half is column 2h + (q ^ swap)
     // the words of half tile (J, h): four 16-byte loads, one per row pair
     auto request = [&](int J, int h, u32x4 (&dst)[4]) {
 #pragma unroll
@@ -289,7 +321,8 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
     unsigned cnt_wave = 0, cnt_unit2 = 0;   // err_unit, cnt_unit2: twice the sum / count (the diagonal square counts once per visit)
     // the lane's four column records come from LDS one column ahead of their use -- the first column's at the end of
     // the previous tile, behind the write that hands its block over
-    auto read_rec = [&](int J, int col, float (&f)[W]) {
+    auto read_rec = [&](int J, int idx, float (&f)[W]) {   // the lane's idx-th column of the tile, in ITS order
+      const int col = idx ^ swap;
       const uint4* cp = &lds[wave][J & 1][4 * b * kRecVec + b];
 #pragma unroll
       for (int v = 0; v < kRecVec; ++v) {
@@ -340,26 +373,29 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
               sym_pair<DIM, ANYTHR, ERR, ANYTHR, false>(pc, ksc, cgc, pi2[p], ks2[p], cg2[p], w0, w1, racc2[p], cacc2[c], err2, cnt_wave);
           }
         }
-        // column sums over the 8 lanes a = 0..7 of a column group (lane bits 0..2); all eight hold the sum, lane
-        // a = 0 stores it: a buffer store whose offset lies past the buffer's end for the other lanes (dropped by
-        // the bounds check) -- no branch, so the compiler's wait counts for the prefetched words stay exact.  The
-        // diagonal square's sums land in slots nobody reads (symm_apply_kernel sums the tile-rows strictly above a
-        // point's own): there every pair is met from both sides and only the row side counts.
-        float flat[2 * DIM];
+        // column sums over the 8 lanes a = 0..7 of a column group (lane bits 0..2; sym_col_reduce); lanes a = 0 and
+        // a = 1 store a column each: a buffer store whose offset lies past the buffer's end for the other lanes
+        // (dropped by the bounds check) -- no branch, so the compiler's wait counts for the prefetched words stay
+        // exact.  The diagonal square's sums land in slots nobody reads (symm_apply_kernel sums the tile-rows strictly
+        // above a point's own): there every pair is met from both sides and only the row side counts.
+        float first[DIM], second[DIM];
 #pragma unroll
-        for (int q = 0; q < 2 * DIM; ++q) flat[q] = cacc2[q / DIM][q % DIM].x + cacc2[q / DIM][q % DIM].y;
-        sym_col_reduce<2 * DIM>(flat);
+        for (int d = 0; d < DIM; ++d) {
+          first[d] = cacc2[0][d].x + cacc2[0][d].y;
+          second[d] = cacc2[1][d].x + cacc2[1][d].y;
+        }
+        sym_col_reduce<DIM>(first, second);
         const int off0 = col_off + ((J * kSymCols) * DIM + h * 2 * DIM) * 4;
 #pragma unroll
-        for (int q = 0; q < 2 * DIM; q += 4) {
-          if (q + 4 <= 2 * DIM) {
-            const u32x4 pk = {__builtin_bit_cast(uint32_t, flat[q]), __builtin_bit_cast(uint32_t, flat[q + 1]),
-                              __builtin_bit_cast(uint32_t, flat[q + 2]), __builtin_bit_cast(uint32_t, flat[q + 3])};
+        for (int q = 0; q < DIM; q += 4) {
+          if (q + 4 <= DIM) {
+            const u32x4 pk = {__builtin_bit_cast(uint32_t, first[q]), __builtin_bit_cast(uint32_t, first[q + 1]),
+                              __builtin_bit_cast(uint32_t, first[q + 2]), __builtin_bit_cast(uint32_t, first[q + 3])};
             __builtin_amdgcn_raw_buffer_store_b128(pk, col_rsrc, off0 + q * 4, 0, 0);
           } else {
 #pragma unroll
-            for (int t = q; t < 2 * DIM; ++t)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, flat[t]), col_rsrc, off0 + t * 4, 0, 0);
+            for (int t = q; t < DIM; ++t)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, first[t]), col_rsrc, off0 + t * 4, 0, 0);
           }
         }
       };
@@ -544,7 +580,7 @@ __global__ __launch_bounds__(256) void symm_tiles_kernel(const uint32_t* const* 
       w = src[blk][enc_index(row - row0[blk], col, ld)];
     }
     const int a = r >> 3, p = (r & 7) >> 1, e = r & 1, b = c >> 2, h = (c & 3) >> 1, f = c & 1;
-    dst[(((4 * h + p) * 64) + a + 8 * b) * 4 + 2 * f + e] = w;
+    dst[(((4 * h + p) * 64) + a + 8 * b) * 4 + 2 * (f ^ (a & 1)) + e] = w;
   }
 }
 

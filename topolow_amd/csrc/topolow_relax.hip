@@ -275,7 +275,7 @@ struct topolow_session {
     int rec_cur = 0, rec_iter = -1;   // rec[rec_cur] holds the records of iteration rec_iter
     DevBuf<float> rowpart, colpart;
     DevBuf<SymUnit> units;
-    DevBuf<int> wave_first;
+    DevBuf<SymRun> wave_first;     // per wave of the grid: its run of units (relax_symm.h: SymPlan::runs)
     DevBuf<int2> row_units;
     DevBuf<const uint32_t*> src_tab;   // the row blocks the tile-major copy is gathered from (one: the session's own)
     DevBuf<int> src_row0;
@@ -727,11 +727,12 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
     const SymPlan plan = relax_symm_plan(y.npad, y.grid * kSymWaves, t0, t1, &y.seg_first, &y.seg_last);
     y.n_units = (int)plan.units.size();
     y.units.alloc(std::max<size_t>(plan.units.size(), 1));
-    y.wave_first.alloc(plan.wave_first.size());
+    const std::vector<SymRun> runs = plan.runs();
+    y.wave_first.alloc(runs.size());
     y.row_units.alloc(std::max<size_t>(plan.row_units.size(), 1));
     if (!plan.units.empty())
       HIP_TRY(hipMemcpy(y.units.p, plan.units.data(), plan.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(y.wave_first.p, plan.wave_first.data(), plan.wave_first.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(y.wave_first.p, runs.data(), runs.size() * sizeof(SymRun), hipMemcpyHostToDevice));
     if (!plan.row_units.empty())
       HIP_TRY(hipMemcpy(y.row_units.p, plan.row_units.data(), plan.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
     y.src_tab.alloc(src.size());
