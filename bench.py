@@ -165,7 +165,7 @@ def run_single(args):
     # the committed rocprofv3 PMC run of this same command (profiles/, FETCH_SIZE x2 on gfx950 +
     # WRITE_SIZE, per launch); null when the workload is not the profiled one.
     traffic, traffic_src = None, None
-    for prof in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for prof in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             if n != 10000:
                 break
