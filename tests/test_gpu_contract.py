@@ -81,9 +81,10 @@ def check_runs(name, runs, mean_band=None, schedule=None, far_max=0.15):
 
 
 @pytest.mark.parametrize("name", ["syn1500_h3n2params", "cfg3gen_1500", "cfg3gen_2048", "cfg3b_1500", "cfg3gen_1500_lowk",
-                                  "syn1500_ndim2", "syn2000_ndim3_sparse"])
+                                  "syn1500_ndim2", "syn2000_ndim3_sparse", "syn7168_ndim2", "syn7168_ndim3_sparse"])
 def test_slab_schedule_meets_the_contract(name):
-    """The fast path (AUTO above 1024 points): row-owner slabs, fp32, random labels."""
+    """The fast path (AUTO above 1024 points): row-owner slabs, fp32, random labels; the two 7 168-point problems also
+    take the symmetric sweep on their one-stage iterations."""
     call, _ = pp.build(name)
     runs = [_native.optimize_layout_exact_arrays(*layout_call_args(call), seed=1 + s) for s in range(SEEDS)]
     assert all(r.info["schedule"] == "slab" and r.info["precision"] == "f32" for r in runs)
