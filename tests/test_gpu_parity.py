@@ -452,7 +452,7 @@ def test_slab_nonfinite_guard_and_messages():
         _native.optimize_layout_exact_arrays(*args, seed=1, schedule="slab")
     assert ei.value.code == _native.ERR_NONFINITE
     with pytest.raises(_native.NativeError) as ei:
-        _native.optimize_layout_exact_arrays(np.zeros((4, 17)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
+        _native.optimize_layout_exact_arrays(np.zeros((4, 65)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
                                              [0] * 4, [], [], [], [], 5, 1.0, 0.1, 0.1, 1e-4, 5, 3, seed=1,
                                              schedule="slab")
     assert ei.value.code == _native.ERR_UNSUPPORTED
@@ -491,10 +491,58 @@ def test_more_than_ten_dimensions_run_zero_padded(ndim):
     assert f32.final_mae == pytest.approx(sm / cnt, rel=2e-5)
     assert np.allclose(_native.est_distances(f32.positions), numpy_pdist(f32.positions), rtol=1e-14, atol=1e-14)
     with pytest.raises(_native.NativeError) as ei:
-        _native.optimize_layout_exact_arrays(np.zeros((4, 17)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
+        _native.optimize_layout_exact_arrays(np.zeros((4, 65)), np.full((4, 4), np.inf), np.zeros((4, 4), np.int32),
                                              [0] * 4, [], [], [], [], 5, 1.0, 0.1, 0.1, 1e-4, 5, 3, seed=1,
                                              schedule="slab")
     assert ei.value.code == _native.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("ndim", [17, 24, 40, 64])
+def test_more_than_sixteen_dimensions_run_on_the_plain_stage_kernel(ndim):
+    """The reference accepts any ndim (src/optimization.cpp:129).  Beyond 16 coordinates the slab schedule runs on a
+    plain form of the stage kernel (csrc/relax_kernels.h: slab_stage_wide_kernel, instantiated for 32 and 64
+    coordinates, other counts zero-padded): stage for stage against the CPU model in f64 (1e-9), fp32 close to it, the
+    one-shot entry (AUTO takes the slab schedule there whatever n is) with the reported MAE equal to the oracle's edge
+    error of the returned positions, thresholds included, row blocks as well; est_distances; the exact GS schedule and
+    ndim > 64 are refused."""
+    import dataclasses
+    n = 310
+    call, _ = _random_problem(n, ndim, 0.6, seed=ndim, thresholds=0.15, n_iter=6, k0=4.0)
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    want, _k = _model_run(call_r, 11, 4, 6, "f64")
+    scale = np.abs(want - call.initial_positions).max()
+    for precision, tol in (("f64", 1e-9), ("f32", 5e-4)):
+        s = _native.Session(n, ndim, precision=precision)
+        s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+        s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        s.set_positions(call.initial_positions)
+        s.begin(6, call.k0, call.cooling_rate, call.c_repulsion, 1e-12, 1000, 3, 11, 4)
+        s.run()
+        got = s.get_positions()
+        assert got.shape == (n, ndim) and np.abs(got - want).max() <= tol * max(scale, 1.0), precision
+        res = s.finish()
+        sm, cnt = orc.edge_error(res.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        if res.iterations == 6:
+            assert res.final_mae == pytest.approx(sm / cnt, rel=1e-12 if precision == "f64" else 2e-5)
+        s.close()
+    long_call = dataclasses.replace(call, n_iter=300)
+    one = _native.optimize_layout_exact_arrays(*layout_call_args(long_call), seed=3)            # AUTO
+    assert one.info["schedule"] == "slab" and one.positions.shape == (n, ndim) and np.isfinite(one.positions).all()
+    sm, cnt = orc.edge_error(one.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert one.final_mae == pytest.approx(sm / cnt, rel=2e-5)
+    start = orc.edge_error(call.initial_positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert one.final_mae < 0.5 * start[0] / start[1]
+    two = _native.optimize_layout_exact_arrays(*layout_call_args(long_call), seed=3, devices=[0, 0])
+    assert np.array_equal(two.positions, one.positions) and two.iterations == one.iterations
+    est = _native.est_distances(one.positions)
+    assert np.abs(est - numpy_pdist(one.positions)).max() <= 1e-12
+    with pytest.raises(_native.NativeError, match="schedule gs") as ei:
+        _native.optimize_layout_exact_arrays(*layout_call_args(long_call), seed=3, schedule="gs")
+    assert ei.value.code == _native.ERR_UNSUPPORTED
+    if ndim == 64:
+        with pytest.raises(_native.NativeError) as ei:
+            _native.Session(n, 65, precision="f32")
+        assert ei.value.code == _native.ERR_UNSUPPORTED
 
 
 def test_slab_no_measurements_only_repulsion():

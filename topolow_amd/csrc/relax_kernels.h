@@ -588,6 +588,67 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINWAVES) void slab_stage_pipe_k
 }
 
 // ---------------------------------------------------------------------------------------
+// Wide embeddings (ndim > 16; the reference accepts any ndim, src/optimization.cpp:129).  The tuned stage kernel
+// keeps a wave's rows in scalar registers and is instantiated per coordinate count up to 16; beyond that the same
+// stage -- same slabs, same row-owner update, same arithmetic per pair -- runs in this plain form, instantiated for
+// 32 and 64 coordinates (other counts zero-padded, exact).  One wave per row; a lane walks every 64th column of the
+// slab, reads the column's point from global memory (twice: once for the distance, once for the update, so that
+// only the DIM accumulators live in registers) and the row's point from LDS.  Not tuned: such problems are rare
+// (the reference's own parameter search covers ndim 2..10) and small.
+// ---------------------------------------------------------------------------------------
+template <int DIM, typename real>
+__global__ __launch_bounds__(kThreads) void slab_stage_wide_kernel(
+    const uint32_t* __restrict__ denc, int ld, int row_begin, int row_end, int n,
+    const real* __restrict__ pos_in, real* __restrict__ pos_out, const float* __restrict__ gplus, RunState* st,
+    SlabRanges rg, int iter1, double k, double c_rep, real* const* __restrict__ push, int n_push) {
+  if (st != nullptr && st->stopped) return;
+  __shared__ real pi_s[kWaves][DIM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = row_begin + blockIdx.x * kWaves + wave;
+  const int rrow = row < row_end ? row : row_end - 1;      // clamp: result discarded below
+  for (int d = lane; d < DIM; d += 64) pi_s[wave][d] = pos_in[(size_t)rrow * DIM + d];
+  __syncthreads();
+  const real* pi = pi_s[wave];
+  const real g = (real)gplus[rrow];
+  const real ks = (real)(2.0 * k) / ((real)4 * g + (real)k), cg = (real)(0.5 * c_rep) / g;
+  real acc[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) acc[d] = 0;
+  const uint32_t* wrow = denc + enc_index(rrow - row_begin, 0, ld);
+  for (int part = 0; part < 2; ++part) {
+    const int b = part == 0 ? rg.b0 : rg.b1, e = part == 0 ? rg.e0 : rg.e1;
+    for (int c = b + lane; c < e; c += 64) {
+      const real* pc = pos_in + (size_t)c * DIM;
+      real s = 0;
+#pragma unroll 8
+      for (int d = 0; d < DIM; ++d) {
+        const real dx = pc[d] - pi[d];
+        s = fma(dx, dx, s);
+      }
+      const uint32_t w = wrow[enc_col_offset_bytes(c) / 4];
+      const real r = Math<real>::sqrt(s);
+      const real inv = Math<real>::rcp(r + (real)0.01);
+      const real t = (real)bits_f32(w & ~kCodeMask);
+      const uint32_t code = w & kCodeMask;
+      const bool spring = (code == 0u) | ((code == 1u) & (r < t)) | ((code == 2u) & (r > t));
+      const real coef = spring ? (t - r) * inv * ks : inv * inv * inv * cg;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) acc[d] = fma(pc[d] - pi[d], coef, acc[d]);
+    }
+  }
+  bool finite = true;
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const real out = pi[d] - wave_sum<real>(acc[d]);
+    finite = finite && isfinite(out);
+    if (lane == 0 && row < row_end) pos_out[(size_t)row * DIM + d] = out;
+    if (n_push > 0 && row < row_end && lane >= 1 && lane <= n_push) push[lane - 1][(size_t)row * DIM + d] = out;
+  }
+  if (lane == 0 && row < row_end && !finite && st != nullptr) atomicMin(&st->first_nonfinite, iter1);
+  (void)n;
+}
+
+// ---------------------------------------------------------------------------------------
 // Dense MAE pass: the same quantity as the edge MAE (reference src/optimization.cpp:54-81), read
 // from the encoded target block instead of the COO list -- coalesced 16-B target loads and LDS
 // staged points instead of two gathers per edge.  Used when the session has verified that the

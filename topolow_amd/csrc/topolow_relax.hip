@@ -36,10 +36,12 @@ using namespace topolow;
 
 namespace {
 
-constexpr int kMaxDim = 16;
-// kernels are instantiated for 1..10, 12 and 16 coordinates; 11 runs as 12 and 13..15 as 16 with the extra
-// coordinates held at exactly zero (a zero coordinate adds 0 to every distance and receives 0 of every move)
-constexpr int kernel_dim(int ndim) { return ndim <= 10 ? ndim : (ndim <= 12 ? 12 : 16); }
+constexpr int kMaxDim = 64;        // 1..16: the tuned kernels; 17..64: the plain stage kernel (relax_kernels.h: slab_stage_wide_kernel)
+constexpr int kMaxTunedDim = 16;
+// kernels are instantiated for 1..10, 12, 16, 32 and 64 coordinates; 11 runs as 12, 13..15 as 16, 17..31 as 32 and
+// 33..63 as 64 with the extra coordinates held at exactly zero (a zero coordinate adds 0 to every distance and
+// receives 0 of every move)
+constexpr int kernel_dim(int ndim) { return ndim <= 10 ? ndim : (ndim <= 12 ? 12 : (ndim <= 16 ? 16 : (ndim <= 32 ? 32 : 64))); }
 constexpr int kDefaultGsMaxN = 1024;
 
 struct HipError {
@@ -333,7 +335,9 @@ namespace {
     case 10: FN<10>(__VA_ARGS__); break;              \
     case 12: FN<12>(__VA_ARGS__); break;              \
     case 16: FN<16>(__VA_ARGS__); break;              \
-    default: throw HipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 16"}; \
+    case 32: FN<32>(__VA_ARGS__); break;              \
+    case 64: FN<64>(__VA_ARGS__); break;              \
+    default: throw HipError{TOPOLOW_ERR_UNSUPPORTED, "ndim must be between 1 and 64"}; \
   }
 
 struct ProfScope {
@@ -452,6 +456,20 @@ void launch_stage(topolow_session* s, const void* pin, void* pout, RunState* st,
                   int iter1, double k, const void* push = nullptr, int n_push = 0, bool err = false) {
   if (s->rows() <= 0) return;
   ProfScope prof(s, err ? &s->prof_stage_err : &s->prof_stage);
+  if constexpr (DIM > kMaxTunedDim) {      // wide embeddings: the plain stage kernel (never an ERR launch: no dense MAE there)
+    const int blocks = (s->rows() + kWaves - 1) / kWaves;
+    if (s->precision == TOPOLOW_PRECISION_F64)
+      hipLaunchKernelGGL((slab_stage_wide_kernel<DIM, double>), dim3(blocks), dim3(kThreads), 0, s->stream, s->enc.p, s->ld,
+                         s->row_begin, s->row_end, s->n, (const double*)pin, (double*)pout, s->gplus.p, st, rg, iter1, k,
+                         s->c_rep, (double* const*)push, n_push);
+    else
+      hipLaunchKernelGGL((slab_stage_wide_kernel<DIM, float>), dim3(blocks), dim3(kThreads), 0, s->stream, s->enc.p, s->ld,
+                         s->row_begin, s->row_end, s->n, (const float*)pin, (float*)pout, s->gplus.p, st, rg, iter1, k,
+                         s->c_rep, (float* const*)push, n_push);
+    HIP_TRY(hipGetLastError());
+    s->stage_launches += 1;
+    return;
+  } else
   if (s->precision == TOPOLOW_PRECISION_F64) {
     launch_stage_pipe<DIM, double, StageCfg<256, 2, 0, 1>>(s, pin, pout, st, rg, iter1, k, push, n_push, false);
   } else {
@@ -501,8 +519,12 @@ int error_parts(const topolow_session* s) { return s->dense_mae ? s->dense_block
 template <int DIM>
 void launch_edge_error(topolow_session* s, const void* pos, const RunState* st) {
   if (s->dense_mae) {
-    if (s->precision == TOPOLOW_PRECISION_F64) launch_dense_error<DIM, double>(s, pos, st);
-    else launch_dense_error<DIM, float>(s, pos, st);
+    if constexpr (DIM > kMaxTunedDim) {
+      throw HipError{TOPOLOW_ERR_UNSUPPORTED, "dense MAE pass: ndim"};   // (wide sessions never set dense_mae)
+    } else {
+      if (s->precision == TOPOLOW_PRECISION_F64) launch_dense_error<DIM, double>(s, pos, st);
+      else launch_dense_error<DIM, float>(s, pos, st);
+    }
   } else if (s->precision == TOPOLOW_PRECISION_F64) {
     hipLaunchKernelGGL((edge_error_kernel<DIM, double, double>), dim3(s->n_parts),
                        dim3(kThreads), 0, s->stream, (const double*)pos, s->ei.p, s->ej.p,
@@ -645,6 +667,9 @@ struct StreamScope {
 // ---- exact tile Gauss-Seidel iteration (relax_tilegs.h): in place on `pos` -------------------
 template <int DIM>
 void launch_tilegs_iteration(topolow_session* s, void* pos, int iter, double k) {
+  if constexpr (DIM > kMaxTunedDim) {
+    throw HipError{TOPOLOW_ERR_UNSUPPORTED, "schedule gs: ndim must be between 1 and 16 (wider embeddings run the slab schedule)"};
+  } else {
   const int nb = (s->n + kTile - 1) / kTile;
   if ((int)s->bperm.n < nb) s->bperm.alloc(nb);
   hipLaunchKernelGGL(tilegs_perm_kernel, dim3(1), dim3(256), 0, s->stream, s->seed, iter, nb, s->bperm.p,
@@ -669,6 +694,7 @@ void launch_tilegs_iteration(topolow_session* s, void* pos, int iter, double k) 
                        s->n, (float*)pos, s->gplus.p, s->state.p, s->seed, iter, k, s->c_rep);
   s->stage_launches += 1;
   HIP_TRY(hipGetLastError());
+  }
 }
 
 void launch_tilegs_finite(topolow_session* s, const void* pos, int iter1) {
@@ -1311,7 +1337,7 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
         HIP_TRY(hipStreamSynchronize(s->stream));
         unsigned long long h[2];
         HIP_TRY(hipMemcpy(h, d_fp.p, 16, hipMemcpyDeviceToHost));
-        s->dense_mae = (h[0] == fp_total.load()) && (h[1] == (unsigned long long)m);
+        s->dense_mae = (h[0] == fp_total.load()) && (h[1] == (unsigned long long)m) && s->dim <= kMaxTunedDim;
       }
     }
     if (s->dense_mae) {   // the gather fallback is not needed: keep 1-element placeholders
@@ -2396,7 +2422,11 @@ int topolow_optimize_layout_exact(
   int schedule = opt.schedule;
   const int gs_max_n = opt.gs_max_n > 0 ? opt.gs_max_n : kDefaultGsMaxN;
   if (schedule == TOPOLOW_SCHEDULE_AUTO)
-    schedule = n <= gs_max_n ? TOPOLOW_SCHEDULE_GS : TOPOLOW_SCHEDULE_SLAB;
+    schedule = (n <= gs_max_n && ndim <= kMaxTunedDim) ? TOPOLOW_SCHEDULE_GS : TOPOLOW_SCHEDULE_SLAB;
+  if (schedule == TOPOLOW_SCHEDULE_GS && ndim > kMaxTunedDim) {
+    set_err(errbuf, errlen, "schedule gs: ndim must be between 1 and %d (wider embeddings run the slab schedule)", kMaxTunedDim);
+    return TOPOLOW_ERR_UNSUPPORTED;
+  }
 
   // exact GS: one workgroup while the problem fits its LDS, the tile schedule beyond that
   const bool gs_fits_lds =
