@@ -26,7 +26,7 @@ void stage(const real* pin, real* pout, int n, int dim, const double* D, const i
   // threads behind a CPU quota, where a default-sized team turns a millisecond loop into seconds
 #pragma omp parallel for schedule(dynamic, 16) num_threads(8) if (n >= 1024)
   for (int i = 0; i < n; ++i) {
-    real acc[16];
+    real acc[64];
     for (int d = 0; d < dim; ++d) acc[d] = 0;
     const real gi = (real)g[i];
     const real inv_spring = (real)1 / ((real)4 * gi + (real)k);
@@ -34,7 +34,7 @@ void stage(const real* pin, real* pout, int n, int dim, const double* D, const i
     for (int rg = 0; rg < n_ranges; ++rg) {
       for (int c = ranges[2 * rg]; c < ranges[2 * rg + 1]; ++c) {
         if (c == i || c >= n) continue;  // ranges live in the padded column space [0, roundup4(n))
-        real delta[16];
+        real delta[64];
         real s = 0;
         for (int d = 0; d < dim; ++d) {
           delta[d] = pin[(size_t)c * dim + d] - pin[(size_t)i * dim + d];
@@ -73,7 +73,7 @@ int slab_model_stage(const double* pos_in, double* pos_out, int n, int dim, cons
                      int n_ranges, double k, double c_rep, int arith) {
   std::vector<double> g(n);
   for (int i = 0; i < n; ++i) g[i] = degrees[i] + 1.0;
-  if (dim > 16) return 1;
+  if (dim > 64) return 1;
   if (arith == 1) {
     std::vector<float> a((size_t)n * dim), b((size_t)n * dim);
     for (size_t q = 0; q < a.size(); ++q) a[q] = (float)pos_in[q];
@@ -93,7 +93,7 @@ int slab_model_run(const double* pos_in, double* pos_out, int n, int dim, const 
                    const int32_t* T, const int32_t* degrees, const int32_t* plan,
                    const int32_t* n_stages, int max_stages, int n_iter, double k0,
                    double cooling, double c_rep, int arith, double* k_out) {
-  if (dim > 16) return 1;
+  if (dim > 64) return 1;
   std::vector<double> g(n);
   for (int i = 0; i < n; ++i) g[i] = degrees[i] + 1.0;
   const size_t nd = (size_t)n * dim;
