@@ -255,3 +255,40 @@ def test_sharded_symmetric_sweep_whole_run_through_the_one_shot_entry(monkeypatc
         assert x.final_mae == pytest.approx(one.final_mae, rel=1e-3)
     sm, cnt = orc.edge_error(got.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
     assert got.final_mae == pytest.approx(sm / cnt, rel=2e-5)
+
+
+@pytest.mark.parametrize("thread_per_block", ["0", "1"])
+def test_sharded_symmetric_sweep_fuzz(thread_per_block, monkeypatch):
+    """Ragged sizes (tile-rows cut anywhere, fewer tile-rows than blocks, n not a multiple of 8 or 64), 2..6
+    coordinates, thresholds, 2..6 blocks, the size gate at zero: the sharded symmetric sweep against the one-session
+    symmetric sweep of the same seed through the production entry -- same schedule, same arithmetic per pair, partial
+    sums grouped by segment: positions within the fp32 summation band, same verdicts while no check falls on a
+    plateau edge (compared to 1e-3)."""
+    import dataclasses
+    monkeypatch.setenv("TOPOLOW_SHARD_THREAD_PER_BLOCK", thread_per_block)
+    monkeypatch.setenv("TOPOLOW_SYMMETRIC_MIN_N", "0")
+    rng = np.random.default_rng(77)
+    done = 0
+    for case in range(8):
+        n = int(rng.integers(130, 900))
+        dim = int(rng.choice([2, 3, 4, 5, 6]))
+        # a soft spring, so that most iterations are ONE stage (the sweep under test); no early stop
+        call, _ = pp.random_problem(n, dim, float(rng.choice([0.3, 0.7, 0.9])), seed=1000 + case,
+                                    thresholds=float(rng.choice([0.0, 0.2])), n_iter=int(rng.integers(12, 40)),
+                                    k0=float(rng.uniform(0.5, 2.5)), cool=0.01, c_rep=0.01, check_freq=int(rng.integers(1, 5)),
+                                    window=10 ** 6, eps=1e-12)
+        seed = int(rng.integers(1, 2 ** 62))
+        blocks = int(rng.integers(2, 7))
+        try:
+            one = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="slab", precision="f32")
+        except _native.NativeError:
+            continue
+        got = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, devices=[0] * blocks)
+        scale = max(1.0, float(np.abs(one.positions).max()))
+        assert np.abs(got.positions - one.positions).max() <= 2e-5 * scale * call.n_iter, (n, dim, blocks)
+        assert got.final_mae == pytest.approx(one.final_mae, rel=1e-3, abs=1e-9)
+        sm, cnt = orc.edge_error(got.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        if cnt > 0:
+            assert got.final_mae == pytest.approx(sm / cnt, rel=5e-5, abs=1e-9)
+        done += 1
+    assert done >= 5
