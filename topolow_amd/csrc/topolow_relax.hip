@@ -710,8 +710,9 @@ void launch_tilegs_finite(topolow_session* s, const void* pos, int iter1) {
 
 // ---- symmetric sweep (relax_symm.h) ----------------------------------------------------------
 // Which sessions take it: the whole matrix on one GPU (no row block, nothing to push), fp32 slab schedule, ndim
-// 2..6 (the register-tiled kernel keeps four rows' coordinates, constants and sums in VGPRs: 12 x ndim of them), at
-// least 2048 points.  Everything else -- and every multi-stage iteration -- stays on the row-owner stage kernel.
+// 2..6 (the register-tiled kernel keeps eight rows' coordinates, constants and sums in VGPRs: 20 x ndim + 16 of
+// them), at least kSymMinPoints points.  Row-sharded runs shard it over their sessions (sym_sharded_*, below).
+// Everything else -- and every multi-stage iteration -- stays on the row-owner stage kernel.
 template <int DIM> constexpr bool kSymDim = DIM >= 2 && DIM <= 6;
 constexpr int kSymMinPoints = 7168;   // below ~7000 points a resident wave gets fewer than 8 tiles and the row-owner sweep is faster (tests/study/symm_crossover.py)
 
