@@ -471,7 +471,10 @@ __global__ __launch_bounds__(64 * kSymWaves, TOPOLOW_SYM_MINW) void symm_sweep_k
 // column sum is sum (p_i - p_c)... with dx = p_c' - p_i' taken row-side, hence the sign).
 // Writes the positions (row-major n4 x DIM, as every other kernel reads them) and the records of the NEXT
 // iteration (k_next).
-constexpr int kSymApplyParts = 32;   // threads of the apply kernel: 32 parts x 32 points (a column block)
+#ifndef TL_APPLY_PARTS
+#define TL_APPLY_PARTS 16
+#endif
+constexpr int kSymApplyParts = TL_APPLY_PARTS;   // threads of the apply kernel: 16 parts x 32 points (a column block); a wave = 2 parts
 template <int DIM>
 __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
     const float* __restrict__ rec, float* __restrict__ rec_next, float* __restrict__ pos_out, const float* __restrict__ gplus,
@@ -479,14 +482,16 @@ __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
     int npad, double k_next, double c_rep, int iter1, RunState* st) {
   if (st != nullptr && st->stopped) return;
   constexpr int W = SymRec<DIM>::W;
-  __shared__ float red[kSymApplyParts][kSymCols][DIM];
+  constexpr int kWavesA = kSymApplyParts / 2;
+  __shared__ float red[kWavesA][kSymCols][DIM];
   const int R = blockIdx.x >> 1;                   // the tile-row of this column block's points
   const int part = threadIdx.x >> 5, pt = threadIdx.x & 31;
   const int i = blockIdx.x * kSymCols + pt;
   float acc[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc[d] = 0.0f;
-  // column sums of the tile-rows above (added), this thread's share: R' = part, part + 32, ...
+  // column sums of the tile-rows above (added), this thread's share: R' = part, part + 16, ... (independent loads: all
+  // of a thread's strips are in flight together)
   for (int Rp = part; Rp < R; Rp += kSymApplyParts) {
     const float* src = colpart + ((size_t)Rp * npad + i) * DIM;
 #pragma unroll
@@ -499,8 +504,14 @@ __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
 #pragma unroll
     for (int d = 0; d < DIM; ++d) acc[d] -= src[d];
   }
+  // fixed order: the two parts of a wave (lanes l, l + 32), then the waves, then onto the point
 #pragma unroll
-  for (int d = 0; d < DIM; ++d) red[part][pt][d] = acc[d];
+  for (int d = 0; d < DIM; ++d) acc[d] += __shfl_xor(acc[d], 32, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 32) == 0) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) red[wave][pt][d] = acc[d];
+  }
   __syncthreads();
   if (part == 0 && i < n) {
     bool finite = true;
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
     for (int d = 0; d < DIM; ++d) {
       float t = red[0][pt][d];
 #pragma unroll
-      for (int p = 1; p < kSymApplyParts; ++p) t += red[p][pt][d];
+      for (int p = 1; p < kWavesA; ++p) t += red[p][pt][d];
       out[d] = rec[(size_t)i * W + d] + t;
       finite = finite && isfinite(out[d]);
       pos_out[(size_t)i * DIM + d] = out[d];
