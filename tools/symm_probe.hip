@@ -195,6 +195,22 @@ int main(int argc, char** argv) {
     for (auto& h : hist) printf("  %d x%d", h.first, h.second);
     printf("\nlast SIMD ends at %.1f us with %d waves / %d tiles; end time by tiles per SIMD:\n", worst, worst_n, worst_tiles);
     for (auto& kv : end_by_load) printf("   %3d tiles: %4zu SIMDs, end p50 %.1f max %.1f us\n", kv.first, kv.second.size(), pct(kv.second, .5), pct(kv.second, 1));
+    std::map<int, std::vector<double>> end_by_units;      // does a SIMD whose waves hold more units (runs that cross tile-rows) end later?
+    for (auto& kv : by_simd) {
+      int un = 0; double e = 0;
+      for (int w : kv.second) { un += units_of[w]; e = std::max(e, (stv[4 * w + 2] - first) / 100.0); }
+      end_by_units[un].push_back(e);
+    }
+    for (auto& kv : end_by_units) printf("   %3d units: %4zu SIMDs, end p50 %.1f max %.1f us\n", kv.first, kv.second.size(), pct(kv.second, .5), pct(kv.second, 1));
+    {   // ... and by XCD
+      std::map<int, std::vector<double>> end_by_xcc;
+      for (auto& kv : by_simd) {
+        double e = 0;
+        for (int w : kv.second) e = std::max(e, (stv[4 * w + 2] - first) / 100.0);
+        end_by_xcc[(int)(kv.first >> 16)].push_back(e);
+      }
+      for (auto& kv : end_by_xcc) printf("   XCD %d: %4zu SIMDs, end p50 %.1f max %.1f us\n", kv.first, kv.second.size(), pct(kv.second, .5), pct(kv.second, 1));
+    }
     time([&]() { sweep(std::false_type{}); apply(); }, "sweep + apply (steady state)");
     time([&]() { sweep(std::false_type{}); }, "sweep (steady state)");
   }
