@@ -53,7 +53,7 @@ extern "C" {
  *         further than max(4 sd_oracle, 3 %) from the oracle's mean (plain sd 0.9-1.8 x the oracle's, 3.3 x at
  *         N = 2048: DESIGN.md section 2b); the MAE it reports is the reference's edge MAE of the positions
  *         it returns to 2e-5; stop iteration within max(3 sd, 10 %) of the oracle's except on 2-D data
- *         (+55 %, same MAE).  Iterations that are ONE stage (k <= 2.5) of an fp32 problem with ndim 2..6 and
+ *         (+55 %, same MAE).  Iterations that are ONE stage (k <= 3) of an fp32 problem with ndim 2..6 and
  *         >= 7168 points run as a symmetric sweep (csrc/relax_symm.h): the same update -- every
  *         point moved by the sum of its own halves of all its pairs at the positions the previous iteration
  *         left -- with each pair's distance and factor computed once; checked against a CPU model of that
@@ -397,6 +397,46 @@ int topolow_session_controller_step(topolow_session* s, const double* d_total2, 
 int32_t topolow_session_can_fuse_checks(const topolow_session* s);
 int topolow_session_stage_fused(topolow_session* s, const void* d_pos_in, void* d_pos_out, int32_t iter,
                                 double k, double* d_out2, char* errbuf, size_t errlen);
+/* ONE-stage iterations of a row-sharded run as the SYMMETRIC sweep sharded over the processes (one per GPU; fp32,
+ * ndim 2..6, >= 7168 points: csrc/relax_symm.h).  Every unordered pair is visited once instead of twice (reference
+ * src/optimization.cpp:198-283 visits each pair once and moves both ends), so a rank reads half the bytes of its
+ * row-owner sweep.  Rank r of P owns SEGMENT r of the tile list of the upper triangle (equal tile counts), not a
+ * row block, so the caller first brings the rows that hold the segment's tiles together:
+ *   topolow_symm_segment_rows   host only: rows [*row_first, *row_end) of the matrix hold segment `segment` of
+ *                               `n_segments`; returns 0 when a problem of n points has too few tiles to cut
+ *   topolow_session_degree_terms  device float[n]: degree + 1 per point (reference :137-140); a row-block session
+ *                               knows its own rows' -- the caller completes the array over the ranks (all-gather)
+ *   topolow_session_symm_segment_build  d_rows: device words of those rows, n_rows x topolow_session_encoded_ld(s),
+ *                               row-major as in the owners' blocks (topolow_session_encoded_ptr; the caller moved
+ *                               them, e.g. RCCL send/recv); any_threshold: some rank's block holds threshold codes.
+ *                               Builds the tile-major copy of the segment and the sweep's buffers; d_rows may be
+ *                               freed on return.  TOPOLOW_ERR_UNSUPPORTED when the session cannot take the path.
+ * and then, per one-stage iteration `iter` (0-based), between topolow_session_begin and _finish:
+ *   topolow_session_symm_segment_sweep  reads all n positions of d_pos_in, sweeps the segment and leaves the
+ *                               segment's share of every point's move in the session's moves buffer
+ *                               (topolow_session_symm_moves: device float[n][ndim]); d_out2 != NULL: also the
+ *                               segment's share of the MAE of d_pos_in, as topolow_session_stage_fused does
+ *   (the caller sums the moves buffer over the ranks in place -- ONE all-reduce of n x ndim floats, 600 KB at
+ *    BASELINE config 4 -- and d_out2 as for stage_fused)
+ *   topolow_session_symm_segment_apply  d_pos_out[i] = d_pos_in[i] + moves[i] for ALL n points: every rank holds
+ *                               the same sums, so every rank holds the same positions and no gather follows.
+ * Nothing here waits for the device (build does, once). */
+int32_t topolow_symm_segment_rows(int32_t n, int32_t segment, int32_t n_segments, int32_t* row_first,
+                                  int32_t* row_end);
+/* 1 when the session can take the path cut into n_segments (fp32 slab schedule, ndim 2..6, size gate, targets loaded). */
+int32_t topolow_session_symm_segment_eligible(const topolow_session* s, int32_t n_segments);
+float* topolow_session_degree_terms(topolow_session* s);
+/* 1 when some target of the session's block carries a threshold code ('>' / '<'): the any_threshold of the ranks is
+ * the OR of these. */
+int32_t topolow_session_has_thresholds(const topolow_session* s);
+int topolow_session_symm_segment_build(topolow_session* s, int32_t segment, int32_t n_segments, const void* d_rows,
+                                       int32_t row_first, int32_t n_rows, int32_t any_threshold, char* errbuf,
+                                       size_t errlen);
+float* topolow_session_symm_moves(topolow_session* s);
+int topolow_session_symm_segment_sweep(topolow_session* s, const void* d_pos_in, int32_t iter, double k,
+                                       double* d_out2, char* errbuf, size_t errlen);
+int topolow_session_symm_segment_apply(topolow_session* s, const void* d_pos_in, void* d_pos_out, int32_t iter,
+                                       char* errbuf, size_t errlen);
 /* First iteration (1-based) at which one of this block's rows became non-finite, 0 = none. Waits. */
 int topolow_session_first_nonfinite(topolow_session* s, int32_t* iteration);
 /* Partial edge error of this session's edge list on d_pos: (sum, count). Synchronous. */
@@ -480,10 +520,10 @@ int topolow_sessions_run_sharded(topolow_session** sessions, int32_t count, cons
 int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t iter,
                           int32_t* ranges_out, int32_t max_stages);
 /* Stage count the adaptive policy picks for spring constant k in ndim dimensions: the smallest power of two
- * with k / stages <= min(2.5, ndim) (a stage is a Jacobi step, stable for k / stages < 2 ndim). */
+ * with k / stages <= min(3, ndim) (a stage is a Jacobi step, stable for k / stages < 2 ndim). */
 int32_t topolow_slab_stages_for_k(double k, int32_t ndim);
 /* Stage count of iteration `iter` (0-based) when slab_stages = 0: the policy above, and at least 16 stages
- * during the first 16 iterations, while the layout unfolds from its start. */
+ * during the first 8 iterations, while the layout unfolds from its start. */
 int32_t topolow_slab_stages_at(int32_t iter, double k, int32_t ndim);
 /* Visiting order of the GS tournament schedule for iteration `iter`: n(n-1)/2 pairs
  * (a,b) as 2 int32 each, in an order equivalent to what the kernel executes. */

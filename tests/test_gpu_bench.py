@@ -59,9 +59,12 @@ def test_bench_gpus_n_launched_plainly_runs_the_row_sharded_path():
     measures ONE config-4-style embedding row-sharded over them (strong scaling), the independent replicas following
     as a secondary field.  Rehearsal on the one GPU of this box: both ranks on device 0, gloo instead of RCCL (RCCL
     refuses two ranks on one device), 4 096 points."""
-    d = run_bench_env({"TOPOLOW_BENCH_OVERSUBSCRIBE": "1", "TOPOLOW_DIST_BACKEND": "gloo"},
+    d = run_bench_env({"TOPOLOW_BENCH_OVERSUBSCRIBE": "1", "TOPOLOW_DIST_BACKEND": "gloo",
+                       "TOPOLOW_SYMMETRIC_MIN_N": "1024"},       # config 4 is above the size gate, 4 096 points are not
                       "--gpus", "2", "--points", "4096", "--steps", "20", "--warmup", "5", "--min-timed", "0.05",
                       "--no-cpu-baseline")
+    # one-stage iterations ran as the symmetric sweep sharded over the ranks (tile segments, one all-reduce of the moves)
+    assert d["config"]["symmetric_segments"] is True and "symm_sweep_kernel" in d["roofline"]["kernel"]
     assert d["scaling"] == "strong" and d["ranks"] == 2 and d["n_gpus"] == 1      # devices really used: one
     assert d["collective_backend"] == "gloo" and d["rccl_ranks"] == 0
     assert "config 4" in d["config"]["workload"] and d["config"]["parallelism"] == "rows/2"

@@ -83,6 +83,57 @@ class ModelBackend:
             self.stopped = True
             self.iters_run = iter1
 
+    # ---- one-stage iterations as the symmetric sweep sharded over the ranks (sharded.HipBackend.symm_*) ----
+    symm_ready = False
+
+    def symm_prepare(self, rank, world):
+        """Which cells of the upper triangle are this rank's: the tiles (64 rows x 32 columns, tile-row-major from
+        each tile-row's diagonal square on: csrc/relax_symm.h) cut into `world` equal segments.  Cells of the diagonal
+        squares come in both orders with weight 1/2, so the two halves of such a pair may sit in different segments."""
+        n = self.n
+        npad = -(-n // 64) * 64
+        TR, TC = npad // 64, npad // 32
+        total = TR * (TR + 1)
+        i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        R, J = i // 64, j // 32
+        tile = R * TC - R * (R - 1) + (J - 2 * R)
+        mine = (J >= 2 * R) & (i != j) & (tile >= total * rank // world) & (tile < total * (rank + 1) // world)
+        self.cell_weight = np.where(mine, np.where(J < 2 * R + 2, 0.5, 1.0), 0.0)
+        self.symm_ready = True
+
+    def _pair_halves(self, pos, k):
+        """H[i, j] = the move of point i caused by the pair (i, j) at `pos` (reference src/optimization.cpp:203-281)."""
+        c = self.call
+        D, T = np.asarray(c.dissimilarity_matrix, float), np.asarray(c.threshold_matrix)
+        g = np.asarray(c.degrees, float)[:, None] + 1.0
+        delta = pos[None, :, :] - pos[:, None, :]
+        r = np.sqrt((delta ** 2).sum(-1))
+        rs = r + 0.01
+        with np.errstate(invalid="ignore"):
+            spring = np.isfinite(D) & ((T == 0) | ((T == 1) & (r < D)) | ((T == -1) & (r > D)))
+            f = np.where(spring, 2.0 * k * (np.where(spring, D, 0.0) - r) / rs / (4.0 * g + k),
+                         self.c_rep / (2.0 * rs ** 3) / g)
+        np.fill_diagonal(f, 0.0)
+        return -delta * f[:, :, None]
+
+    def symm_sweep(self, pos_in, it, k, with_error):
+        total = self.check_partial(pos_in) if with_error else None
+        if self.stopped:
+            return torch.zeros(self.n * self.ndim, dtype=torch.float64), total
+        H = self._pair_halves(pos_in[: self.n].numpy(), k)
+        w = self.cell_weight
+        moves = (w[:, :, None] * H).sum(1) + (w.T[:, :, None] * H).sum(1)   # cell (i, j): i's half and j's half
+        self.iters_run = max(self.iters_run, it + 1)
+        return torch.from_numpy(moves.reshape(-1).copy()), total
+
+    def symm_apply(self, pos_in, pos_out, moves, it):
+        if self.stopped:
+            return
+        new = pos_in[: self.n] + moves.reshape(self.n, self.ndim)
+        pos_out[: self.n] = new
+        if not torch.isfinite(new).all() and not self.bad:
+            self.bad = it + 1
+
     def poll(self):
         return self.stopped, self.iters_run
 
@@ -97,23 +148,25 @@ class ModelBackend:
         pass
 
 
-def _problem():
-    prob = synthetic.make_problem(151, latent_dim=3, missing=0.6, seed=5)
+def _problem(n=151):
+    prob = synthetic.make_problem(n, latent_dim=3, missing=0.6, seed=5)
     init = synthetic.initial_positions(prob.dissimilarity, 3, 5)
     return core.prepare_layout_call(prob.dissimilarity, 3, 40, 9.0, 0.05, 0.02, 1e-4, 3, init, False, 3, True)
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, n_points=151, symmetric=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    call = _problem()
+    call = _problem(n_points)
     n = call.initial_positions.shape[0]
     b, e, _ = sharded.row_block(n, world, rank)
     E = call.edge_i.shape[0]
     sl = slice(rank * E // world, (rank + 1) * E // world)
     backend = ModelBackend(call, b, e, sl)
+    if symmetric and world > 1:
+        backend.symm_prepare(rank, world)
     coll = sharded.Collectives(world)
     res = sharded.relax_sharded(backend, coll, rank, world, n, call.initial_positions, call.n_iter,
                                 call.k0, call.cooling_rate, call.c_repulsion, call.relative_epsilon,
@@ -133,11 +186,11 @@ def _free_port():
     return p
 
 
-def _launch(world):
+def _launch(world, *extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q) + extra) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=300) for _ in range(world)]
@@ -155,6 +208,31 @@ def test_two_ranks_equal_one_rank():
         assert np.array_equal(rank_out[1], one[1])          # identical positions on every rank
         assert rank_out[2:] == pytest.approx(one[2:], rel=1e-12)
     assert one[6] >= one[3] > 0
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_with_the_symmetric_sweep_equal_one_rank():
+    """One-stage iterations as the symmetric sweep sharded over the ranks (each rank a segment of the tile list, the
+    n x ndim moves all-reduced, every rank moving all points): the same embedding as the row-owner run of one rank up
+    to the order of the f64 sums, the same checks, the same verdict; multi-stage iterations stay row-owner."""
+    n = 300
+    call = _problem(n)
+    its = [it for it in range(call.n_iter)
+           if _native.slab_stages_at(it, call.k0 * (1 - call.cooling_rate) ** it, 3) == 1]
+    assert 5 < len(its) < call.n_iter - 8          # both kinds of iteration take part
+    one = _launch(1, n, False)[0]
+    two = _launch(2, n, True)
+    for rank_out in two:
+        np.testing.assert_allclose(rank_out[1], one[1], rtol=0, atol=1e-10)
+        assert np.array_equal(rank_out[1], two[0][1])       # every rank holds the same embedding, bit for bit
+        assert rank_out[2:] == pytest.approx(one[2:], rel=1e-10)
+    # the segments tile the upper triangle: all weights of a pair add up to one
+    w = np.zeros((n, n))
+    for r in range(3):
+        bk = ModelBackend(call, 0, n, slice(0, 0))
+        bk.symm_prepare(r, 3)
+        w += bk.cell_weight
+    assert np.array_equal(w + w.T, 1.0 - np.eye(n))
 
 
 def test_row_blocks_cover_everything():

@@ -210,6 +210,23 @@ def load() -> C.CDLL:
     lib.topolow_session_load_coo.restype = C.c_int
     lib.topolow_session_load_coo.argtypes = [vp, ip, ip, dp, ip, C.c_int64, ip, C.c_char_p,
                                              C.c_size_t]
+    lib.topolow_symm_segment_rows.restype = C.c_int32
+    lib.topolow_symm_segment_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, ip, ip]
+    lib.topolow_session_has_thresholds.restype = C.c_int32
+    lib.topolow_session_has_thresholds.argtypes = [vp]
+    lib.topolow_session_symm_segment_eligible.restype = C.c_int32
+    lib.topolow_session_symm_segment_eligible.argtypes = [vp, C.c_int32]
+    lib.topolow_session_degree_terms.restype = vp
+    lib.topolow_session_degree_terms.argtypes = [vp]
+    lib.topolow_session_symm_moves.restype = vp
+    lib.topolow_session_symm_moves.argtypes = [vp]
+    lib.topolow_session_symm_segment_build.restype = C.c_int
+    lib.topolow_session_symm_segment_build.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32,
+                                                       C.c_char_p, C.c_size_t]
+    lib.topolow_session_symm_segment_sweep.restype = C.c_int
+    lib.topolow_session_symm_segment_sweep.argtypes = [vp, vp, C.c_int32, C.c_double, vp, C.c_char_p, C.c_size_t]
+    lib.topolow_session_symm_segment_apply.restype = C.c_int
+    lib.topolow_session_symm_segment_apply.argtypes = [vp, vp, vp, C.c_int32, C.c_char_p, C.c_size_t]
     lib.topolow_session_encoded_ptr.restype = vp
     lib.topolow_session_encoded_ptr.argtypes = [vp]
     lib.topolow_session_encoded_ld.restype = C.c_int32
@@ -528,6 +545,16 @@ def cv_sweep(cells: CellList, named: bool, preserve_order: bool, ndims, k0s, coo
                               _ip(ec), C.byref(secs), err, len(err))
     _check(rc, err)
     return hsum, hcnt, its, conv, ec, float(secs.value)
+
+
+def symm_segment_rows(n: int, segment: int, n_segments: int):
+    """Rows (first, end) of the matrix that hold segment `segment` of `n_segments` of the symmetric sweep's tile list;
+    None when a problem of n points has too few tiles to cut (topolow_symm_segment_rows; host only)."""
+    lib = load()
+    a, b = C.c_int32(0), C.c_int32(0)
+    if not lib.topolow_symm_segment_rows(int(n), int(segment), int(n_segments), C.byref(a), C.byref(b)):
+        return None
+    return int(a.value), int(b.value)
 
 
 def shard_rows(n: int, blocks: int):
@@ -909,6 +936,39 @@ class Session:
         _check(self.lib.topolow_session_stage_fused(self._h, C.c_void_p(d_pos_in), C.c_void_p(d_pos_out), int(it),
                                                     float(k), C.c_void_p(d_out2), self._err, len(self._err)),
                self._err)
+
+    # ---- one-stage iterations as the symmetric sweep sharded over the processes (include/topolow_relax.h) ----
+    @property
+    def degree_terms_ptr(self) -> int:
+        """Device float[n]: degree + 1 per point; a row-block session knows its own rows' (the caller completes it)."""
+        return int(self.lib.topolow_session_degree_terms(self._h) or 0)
+
+    @property
+    def has_thresholds(self) -> bool:
+        return bool(self.lib.topolow_session_has_thresholds(self._h))
+
+    def symm_segment_eligible(self, n_segments: int) -> bool:
+        return bool(self.lib.topolow_session_symm_segment_eligible(self._h, int(n_segments)))
+
+    def symm_segment_build(self, segment: int, n_segments: int, d_rows: int, row_first: int, n_rows: int,
+                           any_threshold: bool):
+        _check(self.lib.topolow_session_symm_segment_build(self._h, int(segment), int(n_segments), C.c_void_p(d_rows),
+                                                           int(row_first), int(n_rows), int(bool(any_threshold)),
+                                                           self._err, len(self._err)), self._err)
+
+    @property
+    def symm_moves_ptr(self) -> int:
+        """Device float[n][ndim]: the segment's share of every point's move after symm_segment_sweep."""
+        return int(self.lib.topolow_session_symm_moves(self._h) or 0)
+
+    def symm_segment_sweep(self, d_pos_in: int, it: int, k: float, d_out2: int = 0):
+        _check(self.lib.topolow_session_symm_segment_sweep(self._h, C.c_void_p(d_pos_in), int(it), float(k),
+                                                           C.c_void_p(d_out2) if d_out2 else None, self._err,
+                                                           len(self._err)), self._err)
+
+    def symm_segment_apply(self, d_pos_in: int, d_pos_out: int, it: int):
+        _check(self.lib.topolow_session_symm_segment_apply(self._h, C.c_void_p(d_pos_in), C.c_void_p(d_pos_out),
+                                                           int(it), self._err, len(self._err)), self._err)
 
     def first_nonfinite(self) -> int:
         it = C.c_int32(0)

@@ -286,6 +286,9 @@ struct topolow_session {
     bool seg_thr = false;          // some session of the run holds threshold targets: the classifying instance
     int seg_first = 0, seg_last = -1;   // tile-rows that hold a tile of the segment
     int seg_slots = 0;             // sessions of the run (slots of an inbox)
+    int seg_slot = 0;              // the slot this session's folded partials go to
+    bool seg_caller = false;       // built by topolow_session_symm_segment_build: one slot, one owner (this session's
+                                   // own moves buffer = inbox), the caller sums it over the processes
     DevBuf<float> inbox;           // [seg_slots][npad][ndim]: every session's folded partials of this session's points
     DevBuf<float*> inbox_tab;      // every session's inbox (self included)
     DevBuf<int> own0;              // first row of every session, then n
@@ -887,7 +890,7 @@ void sym_sharded_build(std::vector<topolow_session*>& ss, int b) {
   }
   row0.push_back(s->n);
   auto& y = s->sym;
-  if (y.seg_ready && y.seg_peers == peers && y.seg_thr == any_thr) return;
+  if (y.seg_ready && !y.seg_caller && y.seg_peers == peers && y.seg_thr == any_thr) { y.seg_slot = s->rank; return; }
   HIP_TRY(hipSetDevice(s->device));
   const long long npad = (s->n + kSymRows - 1) & ~(kSymRows - 1);
   const long long TR = npad / kSymRows, total = TR * (TR + 1);
@@ -896,6 +899,8 @@ void sym_sharded_build(std::vector<topolow_session*>& ss, int b) {
   y.ready = false;            // the buffers now describe a segment, not the session's own whole-matrix plan
   y.seg_thr = any_thr;
   y.seg_slots = P;
+  y.seg_slot = s->rank;
+  y.seg_caller = false;
   y.inbox.alloc((size_t)P * y.npad * DIM);
   HIP_TRY(hipMemsetAsync(y.inbox.p, 0, (size_t)P * y.npad * DIM * sizeof(float), s->stream));
   y.own0.alloc(row0.size());
@@ -954,7 +959,7 @@ void sym_sharded_sweep(topolow_session* s, const void* pin, int iter, double k, 
       }
     }
     hipLaunchKernelGGL(symm_partial_kernel<DIM>, dim3(TC), dim3(32 * 32), 0, s->stream, y.rowpart.p, y.colpart.p,
-                       y.row_units.p, y.seg_first, y.seg_last, s->n, y.npad, y.inbox_tab.p, y.own0.p, y.seg_slots, s->rank,
+                       y.row_units.p, y.seg_first, y.seg_last, s->n, y.npad, y.inbox_tab.p, y.own0.p, y.seg_slots, y.seg_slot,
                        s->state.p);
     HIP_TRY(hipGetLastError());
     if (err) s->fused_parts = y.n_units;
@@ -974,6 +979,53 @@ void sym_sharded_apply(topolow_session* s, const void* pin, void* pout, const vo
     hipLaunchKernelGGL(symm_owner_apply_kernel<DIM>, dim3((s->rows() + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
                        (float*)pout, y.inbox.p, y.seg_slots, y.npad, s->row_begin, s->row_end, (float* const*)push, s->n_push,
                        iter + 1, s->state.p);
+    HIP_TRY(hipGetLastError());
+  }
+}
+
+// ---- the same sweep sharded over caller-driven sessions (one process per GPU: topolow_session_symm_segment_*) ----
+// The segment of this session, built from the rows the caller brought together; ONE slot and ONE owner: the folded
+// partials of all n points land in the session's own inbox (the "moves buffer"), which the caller sums over the
+// processes; the apply then moves ALL points from it.
+template <int DIM>
+void sym_segment_build(topolow_session* s, int segment, int P, const uint32_t* d_rows, int row_first, int n_rows,
+                       bool any_thr) {
+  auto& y = s->sym;
+  const long long npad = (s->n + kSymRows - 1) & ~(kSymRows - 1);
+  const long long TR = npad / kSymRows, total = TR * (TR + 1);
+  const long long t0 = total * segment / P, t1 = total * (segment + 1) / P;
+  int rf = -1, rl = -1;
+  (void)relax_symm_plan((int)npad, 1, t0, t1, &rf, &rl);
+  if (rf >= 0 && (row_first > rf * kSymRows || row_first + n_rows < std::min<long long>(s->n, (long long)(rl + 1) * kSymRows)))
+    throw HipError{TOPOLOW_ERR_BAD_ARGUMENT, "symm_segment_build: d_rows does not hold the rows of the segment's tiles"};
+  sym_build<DIM>(s, {d_rows}, {row_first, row_first + n_rows}, any_thr, t0, t1);
+  if (y.seg_first < 0) { y.seg_first = 0; y.seg_last = -1; }
+  y.ready = false;            // the buffers now describe a segment, not the session's own whole-matrix plan
+  y.seg_thr = any_thr;
+  y.seg_slots = 1;
+  y.seg_slot = 0;
+  y.seg_caller = true;
+  y.seg_peers.clear();
+  y.inbox.alloc((size_t)y.npad * DIM);
+  HIP_TRY(hipMemsetAsync(y.inbox.p, 0, (size_t)y.npad * DIM * sizeof(float), s->stream));
+  const int own[2] = {0, s->n};
+  y.own0.alloc(2);
+  HIP_TRY(hipMemcpy(y.own0.p, own, sizeof own, hipMemcpyHostToDevice));
+  float* tab[1] = {y.inbox.p};
+  y.inbox_tab.alloc(1);
+  HIP_TRY(hipMemcpy(y.inbox_tab.p, tab, sizeof tab, hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamSynchronize(s->stream));     // the tile-major copy is complete: the caller may free d_rows
+  y.seg_ready = true;
+}
+
+template <int DIM>
+void sym_segment_apply(topolow_session* s, const void* pin, void* pout, int iter) {
+  if constexpr (!kSymDim<DIM>) {
+    throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
+  } else {
+    auto& y = s->sym;
+    hipLaunchKernelGGL(symm_owner_apply_kernel<DIM>, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
+                       (float*)pout, y.inbox.p, 1, y.npad, 0, s->n, (float* const*)nullptr, 0, iter + 1, s->state.p);
     HIP_TRY(hipGetLastError());
   }
 }
@@ -1779,6 +1831,86 @@ int topolow_session_controller_step(topolow_session* s, const double* d_total2, 
     HIP_TRY(hipSetDevice(s->device));
     launch_controller(s, d_pos, iter1, k_after, nullptr, nullptr, 0, d_total2);
     s->iters_enqueued = std::max(s->iters_enqueued, (int)iter1);
+  });
+}
+
+int32_t topolow_symm_segment_rows(int32_t n, int32_t segment, int32_t n_segments, int32_t* row_first,
+                                  int32_t* row_end) {
+  if (n < 2 || n_segments < 1 || segment < 0 || segment >= n_segments) return 0;
+  const long long npad = ((long long)n + kSymRows - 1) & ~(long long)(kSymRows - 1);
+  const long long TR = npad / kSymRows, total = TR * (TR + 1);
+  if (total < 8ll * n_segments) return 0;
+  int rf = -1, rl = -1;
+  (void)relax_symm_plan((int)npad, 1, total * segment / n_segments, total * (segment + 1) / n_segments, &rf, &rl);
+  if (rf < 0) return 0;
+  if (row_first) *row_first = rf * kSymRows;
+  if (row_end) *row_end = (int32_t)std::min<long long>(n, (long long)(rl + 1) * kSymRows);
+  return 1;
+}
+
+int32_t topolow_session_symm_segment_eligible(const topolow_session* s, int32_t n_segments) {
+  return s && s->sym.allowed && s->schedule == TOPOLOW_SCHEDULE_SLAB && s->precision == TOPOLOW_PRECISION_F32 &&
+                 s->dim >= 2 && s->dim <= 6 && s->dim == s->udim && s->n >= s->sym.min_n && s->gplus.p != nullptr &&
+                 topolow_symm_segment_rows(s->n, 0, n_segments, nullptr, nullptr)
+             ? 1 : 0;
+}
+
+float* topolow_session_degree_terms(topolow_session* s) { return s ? s->gplus.p : nullptr; }
+int32_t topolow_session_has_thresholds(const topolow_session* s) { return s && s->gplus.p && s->any_threshold ? 1 : 0; }
+float* topolow_session_symm_moves(topolow_session* s) { return s && s->sym.seg_caller ? s->sym.inbox.p : nullptr; }
+
+int topolow_session_symm_segment_build(topolow_session* s, int32_t segment, int32_t n_segments, const void* d_rows,
+                                       int32_t row_first, int32_t n_rows, int32_t any_threshold, char* errbuf,
+                                       size_t errlen) {
+  if (!s || !d_rows || n_segments < 1 || segment < 0 || segment >= n_segments || n_rows < 0 || row_first < 0 ||
+      row_first + n_rows > s->n)
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (!topolow_session_symm_segment_eligible(s, n_segments)) {
+    set_err(errbuf, errlen, "this session cannot take the symmetric sweep (fp32 slab schedule, ndim 2..6, at least %d "
+                            "points, targets loaded)", s->sym.min_n);
+    return TOPOLOW_ERR_UNSUPPORTED;
+  }
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    try {
+      TL_DISPATCH_DIM(s->dim, sym_segment_build, s, segment, n_segments, (const uint32_t*)d_rows, row_first, n_rows,
+                      any_threshold != 0);
+    } catch (const HipError&) {      // e.g. the device cannot hold the extra buffers: the session keeps its row-owner sweep
+      auto& y = s->sym;
+      y.tenc.release(); y.rowpart.release(); y.colpart.release(); y.inbox.release();
+      y.seg_ready = false;
+      y.seg_caller = false;
+      throw;
+    }
+  });
+}
+
+int topolow_session_symm_segment_sweep(topolow_session* s, const void* d_pos_in, int32_t iter, double k,
+                                       double* d_out2, char* errbuf, size_t errlen) {
+  if (!s || !d_pos_in || !s->began) return TOPOLOW_ERR_BAD_ARGUMENT;
+  if (!(s->sym.seg_ready && s->sym.seg_caller)) {
+    set_err(errbuf, errlen, "no segment built (topolow_session_symm_segment_build)");
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  }
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    TL_DISPATCH_DIM(s->dim, sym_sharded_sweep, s, d_pos_in, iter, k, d_out2 != nullptr);
+    if (d_out2 != nullptr) {
+      hipLaunchKernelGGL(reduce_total_kernel, dim3(1), dim3(1024), 0, s->stream, s->part_sum.p, s->part_cnt.p,
+                         s->sym.tiles > 0 ? s->sym.n_units : 0, d_out2, s->state.p);
+      HIP_TRY(hipGetLastError());
+    }
+    s->iters_enqueued = std::max(s->iters_enqueued, iter + 1);
+  });
+}
+
+int topolow_session_symm_segment_apply(topolow_session* s, const void* d_pos_in, void* d_pos_out, int32_t iter,
+                                       char* errbuf, size_t errlen) {
+  if (!s || !d_pos_in || !d_pos_out || !s->began || !(s->sym.seg_ready && s->sym.seg_caller))
+    return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    TL_DISPATCH_DIM(s->dim, sym_segment_apply, s, d_pos_in, d_pos_out, iter);
   });
 }
 

@@ -107,6 +107,20 @@ class Collectives:
         if self.world > 1:
             self.dist.barrier()
 
+    def move_rows(self, src: int, dst: int, rank: int, send=None, recv=None):
+        """Rows of a device (or host) tensor from rank `src` to rank `dst`: `send` on src, `recv` on dst (both
+        contiguous, same shape), nothing on the others.  Point to point over the backend (RCCL send/recv over xGMI);
+        gloo takes host tensors only, so device tensors are staged."""
+        if rank == src:
+            self.dist.send(send.cpu() if (send.is_cuda and self.backend == "gloo") else send, dst)
+        elif rank == dst:
+            if recv.is_cuda and self.backend == "gloo":
+                host = recv.cpu()
+                self.dist.recv(host, src)
+                recv.copy_(host)
+            else:
+                self.dist.recv(recv, src)
+
     def _host_reduce(self, v: float, op):
         import torch
         dev = "cuda" if self.backend == "nccl" else "cpu"
@@ -191,6 +205,83 @@ class HipBackend:
     def edge_error(self, pos):
         return self.session.edge_error(pos.data_ptr())
 
+    # ---- one-stage iterations as the symmetric sweep sharded over the ranks (include/topolow_relax.h:
+    # topolow_session_symm_segment_*) ----
+    symm_ready = False
+
+    def symm_prepare(self, coll: Collectives, rank: int, world: int) -> bool:
+        """Brings the rows that hold this rank's segment of the upper triangle's tile list together (point to point
+        from their owners), completes the degree terms over the ranks and builds the segment.  Collective: every
+        rank calls it, and either all ranks take the path or none (a rank whose device cannot hold the extra buffers
+        vetoes it).  TOPOLOW_SHARD_SYMMETRIC=0 keeps the row-owner sweep."""
+        torch, s, n = self.torch, self.session, self.n
+        self.symm_ready = False
+        if world < 2 or os.environ.get("TOPOLOW_SHARD_SYMMETRIC", "1") == "0":
+            return False
+        vote = torch.tensor([1.0 if s.symm_segment_eligible(world) else 0.0], dtype=torch.float32, device=self.device)
+        coll.all_reduce_tensor(vote)
+        if vote.item() < world:
+            return False
+        needs = [_native.symm_segment_rows(n, r, world) for r in range(world)]
+        blocks = [row_block(n, world, r)[:2] for r in range(world)]
+        ld = s.encoded_ld
+        g = _as_tensor(torch, s.degree_terms_ptr, (n,), torch.float32, self.device)
+        b, e = blocks[rank]
+        full = torch.zeros(n, dtype=torch.float32, device=self.device)
+        full[b:e] = g[b:e]
+        coll.all_reduce_tensor(full)
+        g.copy_(full)
+        flag = torch.tensor([1.0 if s.has_thresholds else 0.0], dtype=torch.float32, device=self.device)
+        coll.all_reduce_tensor(flag)
+        any_thr = bool(flag.item() > 0)
+        enc = _as_tensor(torch, s.encoded_ptr, (e - b, ld), torch.int32, self.device)
+        first, end = needs[rank]
+        ok = 1.0
+        try:
+            stage = torch.empty((end - first, ld), dtype=torch.int32, device=self.device)
+        except RuntimeError:
+            ok, stage = 0.0, None
+        vote = torch.tensor([ok], dtype=torch.float32, device=self.device)
+        coll.all_reduce_tensor(vote)
+        if vote.item() < world:
+            return False
+        for dst in range(world):            # the same order on every rank: a transfer at a time, no cycle to wait in
+            nf, ne = needs[dst]
+            for src in range(world):
+                lo, hi = max(nf, blocks[src][0]), min(ne, blocks[src][1])
+                if hi <= lo:
+                    continue
+                if src == dst:
+                    if rank == dst:
+                        stage[lo - nf:hi - nf] = enc[lo - b:hi - b]
+                elif rank in (src, dst):
+                    coll.move_rows(src, dst, rank, send=enc[lo - b:hi - b] if rank == src else None,
+                                   recv=stage[lo - nf:hi - nf] if rank == dst else None)
+        ok = 1.0
+        try:
+            s.symm_segment_build(rank, world, stage.data_ptr(), first, end - first, any_thr)
+        except _native.NativeError:
+            ok = 0.0
+        del stage
+        vote = torch.tensor([ok], dtype=torch.float32, device=self.device)
+        coll.all_reduce_tensor(vote)
+        if vote.item() < world:
+            return False
+        self._moves = _as_tensor(torch, s.symm_moves_ptr, (n * self.ndim,), torch.float32, self.device)
+        self.symm_ready = True
+        return True
+
+    def symm_sweep(self, pos_in, it, k, with_error: bool):
+        """This rank's segment of iteration `it`: returns (moves, total2) -- the session's moves buffer (the caller
+        sums it over the ranks in place) and, with_error, the segment's share of the MAE of pos_in."""
+        self.session.symm_segment_sweep(pos_in.data_ptr(), it, k, self._t2.data_ptr() if with_error else 0)
+        return self._moves, (self._t2 if with_error else None)
+
+    def symm_apply(self, pos_in, pos_out, moves, it):
+        """pos_out = pos_in + moves for ALL points; `moves` is the session's own buffer, summed over the ranks."""
+        assert moves.data_ptr() == self._moves.data_ptr()
+        self.session.symm_segment_apply(pos_in.data_ptr(), pos_out.data_ptr(), it)
+
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -233,7 +324,14 @@ class ShardedRelaxation:
         self.it = 0
         self.stopped = False
         self.ndim = int(np.asarray(initial_positions).shape[1])
-        self.fusable = bool(getattr(backend, "can_fuse_checks", False)) and not timers
+        # a check rides on the next sweep only when EVERY rank's block can carry it (an odd row count cannot): the ranks
+        # must agree, the check's all-reduce is part of the schedule they share
+        self.fusable = coll.min_float(1.0 if getattr(backend, "can_fuse_checks", False) else 0.0) > 0 and not timers
+        # one-stage iterations as the symmetric sweep sharded over the ranks (every pair once; one all-reduce of the
+        # n x ndim moves instead of the all-gather): when the backend built its segment (HipBackend.symm_prepare)
+        self.symmetric = bool(getattr(backend, "symm_ready", False)) and world > 1
+        if self.symmetric:
+            self.fusable = not timers     # the sweep's ERR instance has no even-rows rule
         self.pending = None   # (iter1, k_after, buffer index): a check that rides on the next iteration's single stage
 
     def _n_slots_of(self, it_, k_):
@@ -256,6 +354,30 @@ class ShardedRelaxation:
             if self.pending is not None and not fuse_now:
                 self._separate_check(self.pending[2], self.pending[0], self.pending[1])
                 self.pending = None
+            if self.symmetric and n_slots == 1:
+                cur = self.cur
+                if timers:
+                    backend.synchronize()
+                    t0 = time.perf_counter()
+                moves, total = backend.symm_sweep(pos[cur], it, k, fuse_now)
+                if timers:
+                    backend.synchronize()
+                    t1 = time.perf_counter()
+                coll.all_reduce_tensor(moves)
+                if fuse_now:
+                    coll.all_reduce_tensor(total)
+                    backend.controller_step(total, pos[self.pending[2]], self.pending[0], self.pending[1])
+                    self.pending = None
+                if timers:
+                    backend.synchronize()
+                    t2 = time.perf_counter()
+                backend.symm_apply(pos[cur], pos[cur ^ 1], moves, it)
+                if timers:
+                    backend.synchronize()
+                    self.t_stage += (t1 - t0) + (time.perf_counter() - t2)
+                    self.t_gather += t2 - t1
+                self.cur ^= 1
+                n_slots = 0
             for slot in range(n_slots):
                 cur = self.cur
                 if timers:   # breakdown pass: host-synchronised, so slower than the timed pass
@@ -670,6 +792,13 @@ def _bench_sharded(args, rank, world, local, coll):
     b, e, per = row_block(n, world, rank)
     backend = HipBackend(n, ndim, b, e, local)
     n_edges, scale = load_synthetic_block(backend, n, 3, 0.9, 12345, rank, world)
+    # one-stage iterations as the symmetric sweep sharded over the ranks: every rank gets the rows of its segment of the
+    # upper triangle's tile list from their owners (once), then reads half the bytes per iteration and the ranks
+    # exchange ONE all-reduce of n x ndim floats instead of the all-gather
+    t0 = time.perf_counter()
+    symmetric = backend.symm_prepare(coll, rank, world)
+    torch.cuda.synchronize()
+    symm_setup_s = coll.max_float(time.perf_counter() - t0)
     rng = np.random.Generator(np.random.PCG64(999))
     init = np.zeros((n, ndim))
     init[1:] = np.cumsum(rng.uniform(0.0, 2.0 * scale / n, size=(n - 1, ndim)), axis=0)
@@ -744,9 +873,11 @@ def _bench_sharded(args, rank, world, local, coll):
         "data": "synthetic",
         "config": {"workload": f"config 4: ONE embedding, synthetic N={n}, 90% missing, ndim=3, row-block "
                                f"sharded over {world} rank(s) on {n_gpus} GPU(s), all-gather of position slices per "
-                               "slab stage",
+                               "slab stage" + ("; one-stage iterations as the symmetric sweep over tile segments, one "
+                                               "all-reduce of the n x ndim moves each" if symmetric else ""),
                    "n_points": n, "ndim": ndim, "schedule": "slab", "parallelism": f"rows/{world}",
-                   "edges_rank0": n_edges},
+                   "edges_rank0": n_edges, "symmetric_segments": bool(symmetric),
+                   "symmetric_setup_seconds": symm_setup_s if symmetric else None},
         "timing": {"job_iterations": n_job, "slices_per_rotation": P, "rotations": len(rotations),
                    "timed_seconds": float(sum(map(sum, rotations))),
                    "iterations_per_s": {"min": min(rates), "median": float(np.median(rates)), "max": max(rates)},
@@ -759,7 +890,10 @@ def _bench_sharded(args, rank, world, local, coll):
                       "converged": bool(job.converged), "best_iteration": int(job.iterations),
                       "final_mae": job.final_mae},
         "roofline": {"bound": "hbm", "achieved": per_rank[0]["achieved"], "peak": 8000.0, "unit": "GB/s",
-                     "frac": per_rank[0]["frac"], "traffic": None, "kernel": "slab_stage_pipe_kernel<3,float>",
+                     "frac": per_rank[0]["frac"], "traffic": None,
+                     "kernel": ("slab_stage_pipe_kernel<3,float> (multi-stage iterations) + symm_sweep_kernel<3> / "
+                                "symm_partial_kernel<3> / symm_owner_apply_kernel<3> (one-stage iterations)"
+                                if symmetric else "slab_stage_pipe_kernel<3,float>"),
                      "per_gpu_frac": [round(r["frac"], 4) for r in per_rank],
                      "note": "per rank: algorithmic bytes of its row block over the job / its host-synchronised "
                              "stage-kernel time (breakdown pass); `frac` is rank 0's"},
