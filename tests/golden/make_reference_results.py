@@ -3,19 +3,22 @@
 
   inst/examples/comparison_results/coordinates/topolow_H3N2_coords.csv   285 x 5 embedding of BASELINE config 2's panel
   inst/examples/comparison_results/coordinates/topolow_HIV_coords.csv    335 x 2 embedding of config 5's panel
+  inst/examples/comparison_results/coordinates/topolow_DENV_coords.csv   83 x 10 embedding of the DENV panel
       (written by inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:902-923: euclidean_embedding(..., ndim = N,
        mapping_max_iter = 500, relative_epsilon = 1e-10, convergence_counter = 3) at the parameters
        get_optimal_topolow_params() picks from the shipped chains, :622-658)
   inst/examples/comparison_results/fold_stats.csv        per-fold out-of-sample MAE, 20 folds x {H3N2, HIV} (:1872-1912, :2024-2028)
   inst/examples/comparison_results/error_summary.csv     the pooled numbers BASELINE.md quotes (0.799 / 1.315)
-  inst/examples/model_parameters/{H3N2_2003_data_AMC20[1235],HIV_BC_AMC20[2456]}_model_parameters.csv
+  inst/examples/model_parameters/{H3N2_2003_data_AMC20[1235],HIV_BC_AMC20[2456],denv_data_AMC10[1-5]}_model_parameters.csv
       the adaptive-sampling chains: one row per likelihood_function() call of the reference
       (log parameters -> Holdout_MAE, NLL; 20 folds, mapping_max_iter 500, relative_epsilon 1e-4:
       inst/examples/parameter-fitting-h3n2.Rmd:186-207).  From them:
         chain_optimum.json       the parameter set the notebook's rule selects (rows with finite values and
                                  log_N >= log 2, every column cleaned with clean_data(k = 3.5) = median +- 3.5 MAD,
-                                 then argmin Holdout_MAE) -- it has N = 5 for H3N2 and N = 2 for HIV, the widths of
-                                 the two coordinate files;
+                                 then argmin Holdout_MAE) -- it has N = 5 for H3N2, N = 2 for HIV and N = 10 for
+                                 DENV, the widths of the three coordinate files; for DENV it IS the parameter set
+                                 the notebook lists (:326-331: 7.1, 0.01232407, 0.03830152), digit for digit --
+                                 which pins this restatement of the selection rule;
         chain_sample_<DS>.csv    48 rows of the cleaned chain, evenly spaced in the order of Holdout_MAE (the
                                  optimum first): reference-held (parameters -> CV score) pairs.
 
@@ -35,7 +38,8 @@ REF = "/root/reference/inst/examples"
 CHAINS = {
     "H3N2": ["H3N2_2003_data_AMC201", "H3N2_2003_data_AMC202", "H3N2_2003_data_AMC203", "H3N2_2003_data_AMC205"],
     "HIV": ["HIV_BC_AMC202", "HIV_BC_AMC204", "HIV_BC_AMC205", "HIV_BC_AMC206"],
-}   # methods-comparison-h3n2-hiv-denv.Rmd:577-591
+    "DENV": ["denv_data_AMC101", "denv_data_AMC102", "denv_data_AMC103", "denv_data_AMC104", "denv_data_AMC105"],
+}   # methods-comparison-h3n2-hiv-denv.Rmd:577-599
 COLS = ("Holdout_MAE", "NLL", "log_N", "log_k0", "log_cooling_rate", "log_c_repulsion")
 N_SAMPLE = 48
 
@@ -70,6 +74,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for rel in ("comparison_results/coordinates/topolow_H3N2_coords.csv",
                 "comparison_results/coordinates/topolow_HIV_coords.csv",
+                "comparison_results/coordinates/topolow_DENV_coords.csv",
                 "comparison_results/fold_stats.csv", "comparison_results/error_summary.csv"):
         dst = os.path.join(OUT, os.path.basename(rel))
         shutil.copyfile(os.path.join(REF, rel), dst)

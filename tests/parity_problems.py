@@ -81,14 +81,21 @@ def hiv_matrix():
     return antigenic.titers_list_to_matrix(rows, "Virus", "virusYear", "Antibody", None, "distance", sort=True)
 
 
+def denv_matrix():
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "denv_distances.csv"))))
+    return antigenic.titers_list_to_matrix(rows, "virus_strain", "virusYear", "serum_strain", "serumYear",
+                                           "distance", sort=True)
+
+
 # ---- the results the reference itself ships (tests/golden/ref_results/, copied by make_reference_results.py) ----
 REF_RESULTS = os.path.join(GOLD, "ref_results")
 HIV_LISTED = dict(N=2, k0=3.550036, cooling_rate=0.04130713, c_repulsion=0.0007038619)   # ...h3n2-hiv-denv.Rmd:319-323
 H3N2_LISTED = dict(N=4, **H3N2)
+DENV_LISTED = dict(N=10, k0=7.1, cooling_rate=0.01232407, c_repulsion=0.03830152)                # ...h3n2-hiv-denv.Rmd:326-331
 
 
 def ref_coordinates(ds):
-    """(names, positions) of the embedding the reference ships for data set `ds` ("H3N2" | "HIV")."""
+    """(names, positions) of the embedding the reference ships for data set `ds` ("H3N2" | "HIV" | "DENV")."""
     rows = list(csv.reader(open(os.path.join(REF_RESULTS, f"topolow_{ds}_coords.csv"))))
     return [r[0] for r in rows[1:]], np.array([[float(x) for x in r[1:]] for r in rows[1:]])
 
@@ -119,7 +126,7 @@ def ref_matrix(ds):
     """The panel of data set `ds` with its rows in the order of the reference's coordinate file (H3N2: that IS the
     order titers_list_to_matrix builds; HIV: the file lists the viruses in another order), so that a run with
     preserve_order relaxes exactly the problem whose solution the reference holds."""
-    m = core.coded_matrix(h3n2_matrix() if ds == "H3N2" else hiv_matrix())
+    m = core.coded_matrix({"H3N2": h3n2_matrix, "HIV": hiv_matrix, "DENV": denv_matrix}[ds]())
     names, _ = ref_coordinates(ds)
     at = {nm: q for q, nm in enumerate(m.names)}
     perm = np.array([at[nm] for nm in names])
@@ -135,7 +142,8 @@ def refrun_call(ds, params, init_seed=7, init=None, n_iter=500, k0=None):
 
 
 def _refrun(ds, which, init_seed=7):
-    params = ref_chain_optimum(ds) if which == "chain" else dict(HIV_LISTED if ds == "HIV" else H3N2_LISTED)
+    params = ref_chain_optimum(ds) if which == "chain" else dict({"HIV": HIV_LISTED, "H3N2": H3N2_LISTED,
+                                                                    "DENV": DENV_LISTED}[ds])
     if ds == "H3N2":
         params["N"] = 5          # the width of the shipped coordinate file
     return refrun_call(ds, params, init_seed), None
@@ -202,6 +210,10 @@ PROBLEMS = {
                              doc="refrun_call('HIV', chain optimum): ndim 2, k0 8.20, cooling 0.0310, c_rep 0.0194"),
     "hiv_refrun_listed": dict(fn=functools.partial(_refrun, "HIV", "listed"), edges=True, vary_init=True,
                               doc="refrun_call('HIV', listed parameters): ndim 2, k0 3.55, cooling 0.0413, c_rep 0.000704"),
+    # DENV: the chain optimum IS the listed set (make_reference_results.py), so one problem
+    "denv_refrun_chain": dict(fn=functools.partial(_refrun, "DENV", "chain"), edges=True, vary_init=True,
+                              doc="refrun_call('DENV', chain optimum = listed): 83 points, ndim 10, k0 7.10, cooling "
+                                  "0.0123, c_rep 0.0383"),
 }
 
 

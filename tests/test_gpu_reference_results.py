@@ -6,7 +6,8 @@ tests/test_reference_results.py, same fixtures (tests/golden/ref_results/), same
     (0.59241 H3N2, 1.22454 HIV) and against the oracle's 64-run distribution of the same call;
   * warm start from the reference's coordinates: the device has nothing left to do there either;
   * the CV evaluator (one batched launch per data set) at 48 parameter sets for which the reference's chains hold the
-    reference's own Holdout_MAE / NLL, and against fold_stats.csv's 20 per-fold errors.
+    reference's own Holdout_MAE / NLL (H3N2, HIV and the DENV panel), and against fold_stats.csv's 20 per-fold errors;
+  * the DENV panel (10-D): the device against the oracle's distribution of the notebook's call.
 """
 import json
 import os
@@ -55,6 +56,28 @@ def test_device_reaches_the_references_own_error(ds, schedule, precision):
         assert got.std(ddof=1) <= 2.0 * sd + 1e-3 * mean, (got.std(ddof=1), sd)
 
 
+def test_device_matches_the_oracle_on_the_denv_panel():
+    """The third panel the reference ships results for (83 points, 10-D, c_repulsion 0.038: the error rises again after
+    the best iteration, so the best-snapshot restore decides the result): 20 device runs of the notebook's call against
+    the oracle's 64 (0.25250 +- 0.0019): mean inside max(3 sd, 1 %), same scatter, same stop.  The reference's DENV
+    coordinate file itself is a later state of that trajectory (tests/test_reference_results.py) and is not a target."""
+    dist = pp.oracle_distribution("denv_refrun_chain")
+    runs = []
+    for s in range(SEEDS):
+        call, _ = pp.PROBLEMS["denv_refrun_chain"]["fn"](100 + s)
+        r = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=500 + s)
+        assert r.info["schedule"] == "gs" and r.converged
+        sm, cnt = orc.edge_error(r.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        assert r.final_mae == pytest.approx(sm / cnt, rel=1e-10)
+        runs.append(r)
+    got = np.array([r.final_mae for r in runs])
+    mean, sd = dist["mean_final_mae"], dist["sd_final_mae"]
+    assert abs(got.mean() - mean) <= max(3 * sd, 0.01 * mean), (got.mean(), mean, sd)
+    assert got.std(ddof=1) <= 2.0 * sd + 1e-3 * mean, (got.std(ddof=1), sd)
+    its = np.array([r.iterations for r in runs])
+    assert abs(its.mean() - dist["mean_iterations"]) <= max(3 * dist["sd_iterations"] / np.sqrt(SEEDS) * 3, 0.1 * dist["mean_iterations"])
+
+
 @pytest.mark.parametrize("ds", ["H3N2", "HIV"])
 @pytest.mark.parametrize("schedule,precision", [("gs", "f64"), ("slab", "f32")])
 def test_reference_embedding_is_a_rest_point_of_the_device(ds, schedule, precision):
@@ -76,12 +99,12 @@ def test_reference_embedding_is_a_rest_point_of_the_device(ds, schedule, precisi
         assert abs(r.final_mae / mae0 - 1) <= tol_mae and move <= tol_move, (r.final_mae, mae0, move)
 
 
-@pytest.mark.parametrize("ds", ["H3N2", "HIV"])
+@pytest.mark.parametrize("ds", ["H3N2", "HIV", "DENV"])
 def test_cv_evaluator_reproduces_the_references_likelihood_calls(ds):
     """The 48 reference likelihood_function() calls per data set, all folds of all sets in ONE launch (960
     embeddings).  Bands as for the oracle (mean ratio 2 %, every call 6 %, implied held-out count 0.5 % / 2.5 %), and
     device against oracle on the same parameter sets (independent fold draws): mean ratio within 1 %."""
-    m = pp.h3n2_matrix() if ds == "H3N2" else pp.hiv_matrix()
+    m = {"H3N2": pp.h3n2_matrix, "HIV": pp.hiv_matrix, "DENV": pp.denv_matrix}[ds]()
     ent = oracle_cv_entries(ds, "chain")
     sets = [e["params"] for e in ent]
     res, secs, n_emb = cv.likelihood_sweep(m, sets, 500, 1e-4, folds=20, rng=np.random.default_rng(2024))
@@ -90,7 +113,10 @@ def test_cv_evaluator_reproduces_the_references_likelihood_calls(ds):
     ref = np.array([e["ref_Holdout_MAE"] for e in ent])
     orc_mae = np.array([e["Holdout_MAE"] for e in ent])
     rel = ours / ref - 1
-    assert abs(rel.mean()) <= 0.02 and np.abs(rel).max() <= 0.06, (rel.mean(), np.abs(rel).max())
+    if ds == "DENV":      # ndim 6..13; the chain's optimum (row 0) is the minimum of 22 260 noisy calls: 12 %
+        assert 0 < rel[0] <= 0.12 and np.abs(rel[1:]).max() <= 0.08 and abs(rel.mean()) <= 0.025, (rel[:3], rel.mean())
+    else:
+        assert abs(rel.mean()) <= 0.02 and np.abs(rel).max() <= 0.06, (rel.mean(), np.abs(rel).max())
     assert abs((ours / orc_mae - 1).mean()) <= 0.01, (ours / orc_mae - 1).mean()
     n_ref = np.array([e["ref_NLL"] for e in ent]) / (1 + np.log(2 * ref))
     n_ours = np.array([r["NLL"] for r in res]) / (1 + np.log(2 * ours))

@@ -9,7 +9,10 @@ The reference's pair order and start positions are unseedable (src/optimization.
 comparisons are distributional; every band is stated where it is asserted.  What is NOT recorded upstream is which of
 two parameter sets wrote the coordinate files -- the ones the notebook lists (inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:312-323)
 or the ones its rule picks from the shipped chains (:622-658; that set has N = 5 for H3N2, the width of the file) --
-both are tested.  GPU twins of these tests: tests/test_gpu_reference_results.py."""
+both are tested.  A third panel, DENV (83 points, 10-D, repeated titrations averaged), pins the input construction,
+the parameter-selection rule (digit for digit) and 48 more likelihood_function() calls; its coordinate file is NOT
+what the reference's current code returns at the listed parameters (test_denv_coordinate_file_is_a_late_state...).
+GPU twins of these tests: tests/test_gpu_reference_results.py."""
 import json
 import os
 
@@ -53,6 +56,24 @@ def test_panels_are_the_ones_the_reference_embedded():
     assert list(h3.names) == n3
     assert sorted(hv.names) == sorted(nv) and len(set(nv)) == 335
     assert list(pp.ref_matrix("HIV").names) == nv
+    # DENV: 1 838 titrations of 752 (virus, serum) pairs -- process_antigenic_data averages the repeats
+    # (R/data_preprocessing.R:631-646) -- 83 points, the coordinate file's rows in titers_list_to_matrix's order
+    nd, pd_ = pp.ref_coordinates("DENV")
+    assert pd_.shape == (83, 10) and list(pp.denv_matrix().names) == nd
+    call, _ = pp.PROBLEMS["denv_refrun_chain"]["fn"](7)
+    assert len(call.edge_i) == 752 and not np.any(np.asarray(call.edge_thresh))
+
+
+def test_selection_rule_reproduces_the_notebooks_listed_denv_parameters():
+    """get_optimal_topolow_params() as restated in tests/golden/make_reference_results.py (finite rows with
+    log_N >= log 2, clean_data(k = 3.5) per column, argmin Holdout_MAE) applied to the five shipped DENV chains
+    (22 260 rows after cleaning) returns the parameter set the notebook prints for DENV
+    (methods-comparison-h3n2-hiv-denv.Rmd:326-331: N 10, k0 7.1, cooling_rate 0.01232407, c_repulsion 0.03830152) to
+    every printed digit.  (For H3N2 and HIV the printed sets predate the shipped chains and differ from the rule's pick.)"""
+    opt = pp.ref_chain_optimum("DENV")
+    assert opt["N"] == pp.DENV_LISTED["N"] and opt["rows_after_cleaning"] == 22260
+    assert round(opt["k0"], 1) == 7.1 and round(opt["cooling_rate"], 8) == 0.01232407
+    assert round(opt["c_repulsion"], 8) == 0.03830152
 
 
 @pytest.mark.parametrize("ds,which", CANDIDATES)
@@ -135,13 +156,49 @@ def test_oracle_cv_fixture_is_what_the_oracle_computes():
     assert r["mean_iter"] == e["mean_iter"] and r["pct_converged"] == e["pct_converged"]
 
 
-@pytest.mark.parametrize("ds", ["H3N2", "HIV"])
+def test_denv_coordinate_file_is_a_late_state_of_the_oracles_trajectory_not_its_result():
+    """topolow_DENV_coords.csv is examined, not claimed: its edge MAE on the DENV panel is 0.28363, the oracle's result
+    for the call that is said to have written it (listed = chain-optimum parameters, 500 iterations, eps 1e-10,
+    window 3) is 0.25250 +- 0.0019 over 64 runs (best iteration ~150, k ~ 1.1), and none of the other shipped DENV
+    chains' optima gives more than 0.265.  What the file matches is a LATER state of the same trajectory: with
+    c_repulsion 0.038 the error rises again once the spring has cooled (0.2525 at iteration ~170, 0.284 at ~375 where
+    k ~ 0.07, 0.39 at 500) and the current code restores the best snapshot (src/optimization.cpp:368-374) -- the file
+    was evidently written without that restore (an earlier package version; the chunk is eval = FALSE).  Asserted:
+    (1) the MAE itself; (2) it lies between the oracle's best and its no-restore end state; (3) warm-started at
+    k = 0.2 the file is within 1.5 % of a rest point of the oracle's forces and the error then RISES, as it does
+    after the oracle's own best iteration; (4) the measured pairs' distances are the oracle's mean map to 3.5 % (the
+    oracle's own runs: 1 %) -- the same map, inflated by the late repulsion.  The H3N2 / HIV files carry small
+    c_repulsion (0.012 / 0.0007): there the late state and the best state coincide and the files ARE pins."""
+    import dataclasses
+    names, P = pp.ref_coordinates("DENV")
+    call, _ = pp.PROBLEMS["denv_refrun_chain"]["fn"](7)
+    mae, _ = ref_edge_mae("DENV", call)
+    assert mae == pytest.approx(0.2836262225, rel=1e-9)
+    dist = pp.oracle_distribution("denv_refrun_chain")
+    assert dist["n_seeds"] >= 64 and mae > dist["mean_final_mae"] + 10 * dist["sd_final_mae"]
+    free = dataclasses.replace(call, convergence_window=10 ** 6)
+    tr = np.asarray(orc.optimize_layout_exact(*layout_call_args(free), seed=3).mae_trace)
+    assert tr.min() < 0.26 < mae < tr[-1] and tr[-1] > 0.35
+    late = int(np.argmax((tr > mae) & (np.arange(tr.size) > tr.argmin()))) * 3 + 3
+    assert 330 <= late <= 420, late                                  # the iteration whose state has the file's error
+    warm = pp.refrun_call("DENV", pp.ref_chain_optimum("DENV"), init=core.RMatrix(P, names), n_iter=60, k0=0.2)
+    r = orc.optimize_layout_exact(*layout_call_args(warm), seed=0)
+    assert abs(r.final_mae / mae - 1) <= 0.015 and r.mae_trace[5] > r.mae_trace[2]
+    ei, ej = np.asarray(call.edge_i), np.asarray(call.edge_j)
+    d_ref = np.linalg.norm(P[ei] - P[ej], axis=1)
+    d_mean = np.array(dist["edge_dist_mean"])
+    assert float(np.mean(np.abs(d_ref - d_mean)) / d_mean.mean()) <= 0.035
+
+
+@pytest.mark.parametrize("ds", ["H3N2", "HIV", "DENV"])
 def test_oracle_cv_reproduces_the_references_likelihood_calls(ds):
     """48 likelihood_function() calls of the reference per data set (its adaptive-sampling chains: parameters ->
     Holdout_MAE, NLL; 20 folds, 500 iterations, eps 1e-4) re-evaluated with the oracle in the fold evaluator of
     R/adaptive_sampling.R:2552-2726.  Fold draws, start positions and pair order are random on both sides: one call's
     Holdout_MAE scatters by ~1.5 %.  Measured ratio oracle / reference - 1: H3N2 mean +1.3 % (sd 1.7 %, max 4.9 %),
-    HIV mean -0.2 % (sd 1.2 %, max 4.6 %).  Bands: mean 2 %, every call 6 %.  The pooled number of held-out numeric
+    HIV mean -0.2 % (sd 1.2 %, max 4.6 %), DENV (83 points, 38 held-out pairs per fold: one call scatters by 2.4 %)
+    mean +1.7 %, max 6.2 % -- and 9.9 % for the chain's optimum itself, the minimum of 22 260 noisy calls, which
+    cannot be reproduced by an independent draw (its band: 12 %).  Bands: mean 2 %, every call 6 % (DENV 7 %).  The pooled number of held-out numeric
     cells implied by the reference's own (Holdout_MAE, NLL) pair, n = NLL / (1 + log(2 MAE)), pins the fold-size rule
     and the exclusion of threshold cells (R/error_metrics.R:90-91): it varies with the draw (how many threshold
     cells a fold happens to hold), so the means over the 48 calls are compared (0.5 %) and every call to 2.5 %."""
@@ -150,7 +207,11 @@ def test_oracle_cv_reproduces_the_references_likelihood_calls(ds):
     ours = np.array([e["Holdout_MAE"] for e in ent])
     ref = np.array([e["ref_Holdout_MAE"] for e in ent])
     rel = ours / ref - 1
-    assert abs(rel.mean()) <= 0.02 and np.abs(rel).max() <= 0.06, (rel.mean(), np.abs(rel).max())
+    if ds == "DENV":
+        assert ref[0] == ref.min() and 0 < rel[0] <= 0.12 and np.abs(rel[1:]).max() <= 0.07, rel[:3]
+        assert abs(rel.mean()) <= 0.02, rel.mean()
+    else:
+        assert abs(rel.mean()) <= 0.02 and np.abs(rel).max() <= 0.06, (rel.mean(), np.abs(rel).max())
     n_ref = np.array([e["ref_NLL"] for e in ent]) / (1 + np.log(2 * ref))
     n_ours = np.array([e["NLL"] for e in ent]) / (1 + np.log(2 * ours))
     assert np.allclose(n_ref, np.round(n_ref), atol=1e-3)        # the reference's n is an integer count
