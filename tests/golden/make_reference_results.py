@@ -9,6 +9,8 @@
        get_optimal_topolow_params() picks from the shipped chains, :622-658)
   inst/examples/comparison_results/fold_stats.csv        per-fold out-of-sample MAE, 20 folds x {H3N2, HIV} (:1872-1912, :2024-2028)
   inst/examples/comparison_results/error_summary.csv     the pooled numbers BASELINE.md quotes (0.799 / 1.315)
+  inst/examples/comparison_results/error_distribution_HIV_H3N2.csv   mean / sd / quartiles of the SIGNED out-of-sample
+                                                         errors of the same 20 folds pooled (:2339-2349)
   inst/examples/model_parameters/{H3N2_2003_data_AMC20[1235],HIV_BC_AMC20[2456],denv_data_AMC10[1-5]}_model_parameters.csv
       the adaptive-sampling chains: one row per likelihood_function() call of the reference
       (log parameters -> Holdout_MAE, NLL; 20 folds, mapping_max_iter 500, relative_epsilon 1e-4:
@@ -75,7 +77,8 @@ def main():
     for rel in ("comparison_results/coordinates/topolow_H3N2_coords.csv",
                 "comparison_results/coordinates/topolow_HIV_coords.csv",
                 "comparison_results/coordinates/topolow_DENV_coords.csv",
-                "comparison_results/fold_stats.csv", "comparison_results/error_summary.csv"):
+                "comparison_results/fold_stats.csv", "comparison_results/error_summary.csv",
+                "comparison_results/error_distribution_HIV_H3N2.csv"):
         dst = os.path.join(OUT, os.path.basename(rel))
         shutil.copyfile(os.path.join(REF, rel), dst)
         os.chmod(dst, 0o644)

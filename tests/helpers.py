@@ -54,7 +54,7 @@ def oracle_cv(matrix, params, folds, rng, mapping_max_iter=500, relative_epsilon
     from topolow_amd import cv
     m = core.coded_matrix(matrix)
     n = m.values.shape[0]
-    rows = []
+    rows, signed = [], []
     for f, h in enumerate(cv.make_folds(m.values, folds, rng)):
         masked = m.masked(h % n, h // n)
         call = core.prepare_layout_call(masked, int(params["N"]), mapping_max_iter, params["k0"],
@@ -67,6 +67,14 @@ def oracle_cv(matrix, params, folds, rng, mapping_max_iter=500, relative_epsilon
         oe = oe[~np.isnan(oe)]
         rows.append(dict(n_samples=int(oe.size), sum_abs_errors=float(np.abs(oe).sum()), iter=int(r.iterations),
                          converged=int(r.converged)))
+        signed.append(oe)
     out = cv._pooled([rows])[0]
     out["fold_mae"] = [r["sum_abs_errors"] / r["n_samples"] for r in rows if r["n_samples"] > 0]
+    # the SIGNED out-of-sample errors of all folds pooled, summarised as the reference's notebook does
+    # (inst/examples/methods-comparison-h3n2-hiv-denv.Rmd:2339-2349 -> comparison_results/error_distribution_HIV_H3N2.csv;
+    # quantile() type 7 = numpy's default)
+    e = np.concatenate(signed) if signed else np.zeros(0)
+    if e.size > 1:
+        out["signed"] = dict(Mean=float(e.mean()), SD=float(e.std(ddof=1)), Median=float(np.median(e)),
+                             Q1=float(np.quantile(e, 0.25)), Q3=float(np.quantile(e, 0.75)), n=int(e.size))
     return out

@@ -121,6 +121,14 @@ def ref_fold_stats(ds, algorithm="Topolow"):
     return np.array([float(r["OutSampleError"]) for r in rows if r["Dataset"] == ds and r["Algorithm"] == algorithm])
 
 
+def ref_error_distribution(ds, algorithm="Topolow"):
+    """Mean, SD, Median, Q1, Q3 of the reference's pooled signed out-of-sample errors (error_distribution_HIV_H3N2.csv)."""
+    for r in csv.DictReader(open(os.path.join(REF_RESULTS, "error_distribution_HIV_H3N2.csv"))):
+        if r["Dataset"] == ds and r["Algorithm"] == algorithm:
+            return {k: float(r[k]) for k in ("Mean", "SD", "Median", "Q1", "Q3")}
+    raise KeyError(ds)
+
+
 @functools.lru_cache(maxsize=4)
 def ref_matrix(ds):
     """The panel of data set `ds` with its rows in the order of the reference's coordinate file (H3N2: that IS the

@@ -149,3 +149,31 @@ def test_cv_evaluator_reproduces_the_references_fold_errors(ds):
         pooled.append(f)
     pooled = np.concatenate(pooled)
     assert abs(pooled.mean() / ref.mean() - 1) <= 0.03, (pooled.mean(), ref.mean())
+
+
+@pytest.mark.parametrize("ds", ["H3N2", "HIV"])
+def test_device_cv_reproduces_the_references_signed_error_distribution(ds):
+    """error_distribution_HIV_H3N2.csv (mean, sd, quartiles of the reference's pooled SIGNED out-of-sample errors, 20
+    folds) against the product's own pieces in the notebook's procedure: folds cut by cv.make_folds, every fold relaxed
+    on the device through the `.Call` payload (500 iterations, eps 1e-10, window 3), distances by the device's
+    est_distances, errors by cv.error_calculator_comparison (true - predicted, R/error_metrics.R:113).  Same bands as
+    the oracle's test (tests/test_reference_results.py: SIGNED_BANDS, sd 4 %)."""
+    from tests.test_reference_results import check_signed_distribution
+    m = core.coded_matrix(pp.h3n2_matrix() if ds == "H3N2" else pp.hiv_matrix())
+    params = best_params(ds)
+    n = m.values.shape[0]
+    rng = np.random.default_rng(8)
+    signed = []
+    for f, h in enumerate(cv.make_folds(m.values, 20, rng)):
+        masked = m.masked(h % n, h // n)
+        call = core.prepare_layout_call(masked, int(params["N"]), 500, params["k0"], params["cooling_rate"],
+                                        params["c_repulsion"], 1e-10, 3, None, False, 3, False, rng)
+        r = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=900 + f)
+        err = cv.error_calculator_comparison(_native.est_distances(r.positions), m, masked, pred_names=call.names,
+                                             true_names=m.names)
+        oe = err["OutSampleError"]
+        signed.append(oe[~np.isnan(oe)])
+    e = np.concatenate(signed)
+    assert e.size > 4000
+    check_signed_distribution(ds, dict(Mean=float(e.mean()), SD=float(e.std(ddof=1)), Median=float(np.median(e)),
+                                       Q1=float(np.quantile(e, 0.25)), Q3=float(np.quantile(e, 0.75))))
