@@ -38,8 +38,9 @@ extern "C" {
  * (tests/test_reference_results.py, data under tests/golden/ref_results/): the edge MAE of the reference's own H3N2
  * and HIV embeddings lies inside the oracle's 64-run distribution of the same call (0.59241 vs 0.58806 +- 0.0037;
  * 1.22454 vs 1.21109 +- 0.0121), those embeddings are rest points of the oracle's relaxation (error moves 0.05 %),
- * 2 x 48 likelihood_function() calls recorded in the reference's chains are reproduced to +1.3 % / -0.2 % in the mean
- * (one call scatters by 1.5 %), its 20 per-fold CV errors to within 3 standard errors.  What this library guarantees,
+ * 3 x 48 likelihood_function() calls recorded in the reference's chains (H3N2, HIV, DENV) are reproduced to +1.3 % /
+ * -0.2 % / +1.7 % in the mean (one call scatters by 1.5-2.4 %), its 20 per-fold CV errors to within 3 standard errors,
+ * the mean, sd and quartiles of its pooled signed out-of-sample errors in sign and size.  What this library guarantees,
  * and tests (tests/test_gpu_contract.py against >= 20 oracle seeds per problem committed under tests/golden/;
  * tests/test_gpu_reference_results.py against the reference-held numbers directly):
  *   GS    the reference's arithmetic pair by pair in f64, in round-robin tournament order; the CPU oracle
