@@ -135,7 +135,15 @@ def run_single(args):
                 if got == 0:
                     break
                 done += got
-            _iters, stopped, _mae = s.sync()
+            # a slice ends when its launches have completed; a convergence check that is waiting to ride on the next
+            # iteration's sweep stays pending across the slice boundary, exactly as in the uninterrupted job (forcing
+            # it would add a separate error pass the job never runs); the LAST slice flushes it, so every check of
+            # the job is inside a timed slice
+            stopped = False
+            if _p + 1 < P:
+                s.wait()
+            else:
+                _iters, stopped, _mae = s.sync()
             torch.cuda.synchronize()
             slices.append(time.perf_counter() - t)
             assert done == K and not stopped, (done, stopped)
@@ -253,7 +261,9 @@ def run_single(args):
                            "of exactly K iterations, each between two device synchronisations, after W untimed "
                            "iterations of a throw-away run; a rotation times every slice once; value = K / mean slice, median "
                            "over rotations -- the job's average rate whatever K and W are.  by_slice shows the "
-                           "schedule: the first slices hold the 16- and 2-stage iterations"},
+                           "schedule: the first slices hold the 16- and 2-stage iterations.  A convergence check that "
+                           "is waiting to ride on the next iteration's sweep stays pending across a slice boundary, as "
+                           "in the uninterrupted job; the last slice flushes it, so every check lies inside a timed slice"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_refers_to": {"launch": "one one-stage iteration of the dominant kind",

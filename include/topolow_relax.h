@@ -315,7 +315,12 @@ int topolow_session_begin(topolow_session* s, int32_t n_iter, double k0, double 
  * returns without waiting; *enqueued = iterations enqueued (0 when the run is over). */
 int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqueued,
                             char* errbuf, size_t errlen);
-/* Waits for everything enqueued; reports progress. */
+/* Waits for the launches enqueued so far on the session's streams and nothing else: a convergence check that is
+ * waiting to ride on the next iteration's sweep (one-stage iterations reduce the pending check's MAE on the way) stays
+ * pending, as it would in an uninterrupted run; no state is read back.  For callers that pace a run in slices
+ * (bench.py) and go on enqueueing. */
+int topolow_session_wait(topolow_session* s, char* errbuf, size_t errlen);
+/* Waits for everything enqueued, a pending check included (it runs as a separate pass); reports progress. */
 int topolow_session_sync(topolow_session* s, int32_t* iterations_run, int32_t* stopped,
                          double* last_mae, char* errbuf, size_t errlen);
 /* Restores the best snapshot and returns the reference's result fields. */

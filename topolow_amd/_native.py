@@ -216,6 +216,8 @@ def load() -> C.CDLL:
     lib.topolow_session_has_thresholds.argtypes = [vp]
     lib.topolow_session_symm_segment_eligible.restype = C.c_int32
     lib.topolow_session_symm_segment_eligible.argtypes = [vp, C.c_int32]
+    lib.topolow_session_wait.restype = C.c_int
+    lib.topolow_session_wait.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.topolow_session_degree_terms.restype = vp
     lib.topolow_session_degree_terms.argtypes = [vp]
     lib.topolow_session_symm_moves.restype = vp
@@ -811,6 +813,10 @@ class Session:
         _check(self.lib.topolow_session_enqueue(self._h, int(max_iters), C.byref(enq), self._err,
                                                 len(self._err)), self._err)
         return int(enq.value)
+
+    def wait(self):
+        """Waits for the launches enqueued so far; a check waiting to ride on the next sweep stays pending."""
+        _check(self.lib.topolow_session_wait(self._h, self._err, len(self._err)), self._err)
 
     def sync(self):
         it, st, mae = C.c_int32(0), C.c_int32(0), C.c_double(0.0)

@@ -1585,6 +1585,15 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
   });
 }
 
+int topolow_session_wait(topolow_session* s, char* errbuf, size_t errlen) {
+  if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;
+  return guarded(errbuf, errlen, [&] {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s->check_stream));
+  });
+}
+
 int topolow_session_sync(topolow_session* s, int32_t* iterations_run, int32_t* stopped,
                          double* last_mae, char* errbuf, size_t errlen) {
   if (!s) return TOPOLOW_ERR_BAD_ARGUMENT;

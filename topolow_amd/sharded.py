@@ -643,7 +643,10 @@ def _bench_replicas(args, rank, world, local, coll):
             done = 0
             while done < K:
                 done += s.enqueue(K - done)
-            s.sync()
+            if _p + 1 < P:      # as bench.py: run_single -- a check waiting to ride on the next sweep stays pending
+                s.wait()
+            else:
+                s.sync()
             torch.cuda.synchronize()
             coll.barrier()
             slices.append(coll.max_float(time.perf_counter() - t0))
