@@ -72,18 +72,23 @@ def test_config2_slab_schedule_on_h3n2_when_forced():
 
 
 def test_config5_batched_cv_matches_published_holdout_mae():
+    """20-fold CV at the parameters the reference publishes, one batched launch per panel, against the numbers the
+    reference holds: its 20 per-fold errors (comparison_results/fold_stats.csv: H3N2 0.828 +- 0.064, HIV 1.329 +-
+    0.096) -- |difference of the fold means| <= 3 standard errors of the difference -- and the pooled figures of
+    error_summary.csv / BASELINE.md (0.799 / 1.315, computed there after dropping error outliers beyond 3.5 MAD,
+    which lowers them): within 7 %.  Measured: H3N2 0.838, HIV 1.296."""
+    from tests import parity_problems as pp
     rng = np.random.default_rng(11)
-    h3 = h3n2_matrix()
-    res, secs, n_emb = cv.likelihood_sweep(h3, [dict(N=4, **H3N2)], 500, 1e-4, folds=20, rng=rng)
-    r = res[0]
-    assert n_emb == 20 and r["pct_converged"] >= 50
-    assert 0.65 <= r["Holdout_MAE"] <= 0.95, r          # reference publishes 0.799 (20-fold CV)
-    hv = hiv_matrix()
-    res, secs, n_emb = cv.likelihood_sweep(hv, [HIV], 500, 1e-4, folds=20, rng=rng)
-    r = res[0]
-    assert n_emb == 20
-    assert 1.05 <= r["Holdout_MAE"] <= 1.60, r          # reference publishes 1.315 (20-fold CV)
-    assert np.isfinite(r["NLL"]) and 0 < r["mean_iter"] <= 500
+    for m, params, ds, published in ((h3n2_matrix(), dict(N=4, **H3N2), "H3N2", 0.799), (hiv_matrix(), HIV, "HIV", 1.315)):
+        res, secs, n_emb = cv.likelihood_sweep(m, [params], 500, 1e-4, folds=20, rng=rng)
+        r = res[0]
+        assert n_emb == 20 and r["pct_converged"] >= 50
+        f, ref = np.array(r["fold_mae"]), pp.ref_fold_stats(ds)
+        assert f.size == 20 and ref.size == 20
+        se = np.hypot(f.std(ddof=1) / np.sqrt(20), ref.std(ddof=1) / np.sqrt(20))
+        assert abs(f.mean() - ref.mean()) <= 3 * se, (ds, f.mean(), ref.mean(), se)
+        assert abs(r["Holdout_MAE"] / published - 1) <= 0.07, (ds, r["Holdout_MAE"], published)
+        assert np.isfinite(r["NLL"]) and 0 < r["mean_iter"] <= 500
 
 
 def test_config5_sweep_many_parameter_sets_in_one_launch():
