@@ -150,10 +150,10 @@ def _with_thresholds(call, frac, seed=3):
     return call
 
 
-def _symmetric_session(call, n, dim, iters, k0, cooling, c_rep, check_freq, profile, relabel=0):
-    """A whole-matrix fp32 session forced onto the symmetric sweep: ONE stage per iteration, no early stop."""
+def _symmetric_session(call, n, dim, iters, k0, cooling, c_rep, check_freq, profile, relabel=0, precision="f32"):
+    """A whole-matrix session forced onto the symmetric sweep: ONE stage per iteration, no early stop."""
     with _Env(TOPOLOW_SYMMETRIC="1", TOPOLOW_SYMMETRIC_MIN_N="0"):
-        s = _native.Session(n, dim, precision="f32")
+        s = _native.Session(n, dim, precision=precision)
     if relabel:
         s.set_relabel(relabel)
     s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
@@ -256,3 +256,60 @@ def test_symmetric_sweep_at_config3_size_against_the_model():
     assert err.mean() <= 5e-5 * scale and err.max() <= 5e-3 * scale, (err.mean() / scale, err.max() / scale)
     sm, cnt = orc.edge_error(want[0], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
     assert int(trace[0, 0]) == 1 and trace[0, 1] == pytest.approx(sm / cnt, rel=2e-5)
+
+
+# ----------------------------------------------------------------------------------------
+# the same sweep in f64 (csrc/relax_symm64.h): the reference's arithmetic type, so the CPU model in f64 is matched to
+# rounding -- a far tighter statement about the tiling (phantom rows and columns, the diagonal squares swept from both
+# sides, units cut anywhere, the swapped column order of odd lane groups) than the fp32 bands allow
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [33, 66, 1000, 2973])
+@pytest.mark.parametrize("dim,thr", [(2, 0.0), (2, 0.15), (3, 0.15), (4, 0.0), (5, 0.0), (5, 0.15), (6, 0.0), (6, 0.15)])
+def test_symmetric_sweep_f64_equals_the_model_to_rounding(n, dim, thr):
+    """One and seven one-stage iterations in f64 against slab_model.stage in f64 (reference update
+    src/optimization.cpp:203-281 on every ordered pair): relative 1e-12 of the displacement scale per iteration (the
+    two differ in the order of the sums and in (t - r) / (r + 0.01) x 2k / (4 g + k) against the model's grouping);
+    the checks (separate passes in f64 sessions) against the oracle's edge error of the model's positions to 1e-12;
+    and against the row-owner f64 stage kernel (TOPOLOW_SYMMETRIC=0) the same band."""
+    k0, cooling, c_rep = 1.5, 0.01, 0.01
+    call, _ = pp.random_problem(n, dim, 0.7 if n > 100 else 0.3, seed=190 + n % 50 + dim, n_iter=7, k0=k0)
+    call = _with_thresholds(call, thr)
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    want = _model_iterations(call_r, 7, k0, cooling, c_rep)
+    scale = np.abs(want[-1] - call.initial_positions).max()
+    for iters in (1, 7):
+        got, trace, counts = _symmetric_session(call, n, dim, iters, k0, cooling, c_rep, 3, profile=True, precision="f64")
+        assert counts[1] == iters and counts[3] == 0, counts     # every iteration a symmetric sweep, no fused check in f64
+        assert np.abs(got - want[iters - 1]).max() <= 1e-12 * scale * iters, np.abs(got - want[iters - 1]).max() / scale
+        if iters == 7:
+            assert [int(t) for t in trace[:, 0]] == [3, 6, 7]
+            for row in trace:
+                sm, c = orc.edge_error(want[int(row[0]) - 1], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+                assert row[1] == pytest.approx(sm / c, rel=1e-11), (row, sm / c)
+    with _Env(TOPOLOW_SYMMETRIC="0"):
+        s = _native.Session(n, dim, precision="f64")
+    s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    s.set_positions(call.initial_positions)
+    s.begin(7, k0, cooling, c_rep, 1e-12, 10 ** 9, 3, 5, 1)
+    s.run()
+    s.sync()
+    row_owner = s.get_positions()
+    s.close()
+    assert np.abs(got - row_owner).max() <= 1e-12 * scale * 7
+
+
+def test_symmetric_sweep_f64_whole_run_at_config3_generator_size():
+    """The production entry in f64 on a 7 400-point problem of the config-3 generator (above the size gate): multi-stage
+    iterations on the row-owner kernel, one-stage iterations on the f64 symmetric sweep, against the same run with the
+    sweep switched off -- the same schedule and arithmetic, sums grouped differently: same stop within two checks, final
+    MAE to 1e-6, and the reported MAE is the oracle's edge error of the returned positions."""
+    call, _ = pp.cfg3_generator(7400)
+    with _Env(TOPOLOW_SYMMETRIC="1"):
+        a = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=3, schedule="slab", precision="f64")
+    with _Env(TOPOLOW_SYMMETRIC="0"):
+        b = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=3, schedule="slab", precision="f64")
+    assert a.converged and b.converged and abs(a.iterations - b.iterations) <= 6
+    assert a.final_mae == pytest.approx(b.final_mae, rel=1e-6)
+    sm, cnt = orc.edge_error(a.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+    assert a.final_mae == pytest.approx(sm / cnt, rel=1e-12)

@@ -31,6 +31,7 @@
 #include "relax_gs.h"
 #include "relax_tilegs.h"
 #include "relax_symm.h"
+#include "relax_symm64.h"
 
 using namespace topolow;
 
@@ -276,6 +277,7 @@ struct topolow_session {
     DevBuf<float> rec[2];
     int rec_cur = 0, rec_iter = -1;   // rec[rec_cur] holds the records of iteration rec_iter
     DevBuf<float> rowpart, colpart;
+    DevBuf<double> rec64[2], rowpart64, colpart64;   // f64 sessions (relax_symm64.h)
     DevBuf<SymUnit> units;
     DevBuf<SymRun> wave_first;     // per wave of the grid: its run of units (relax_symm.h: SymPlan::runs)
     DevBuf<int2> row_units;
@@ -720,7 +722,8 @@ template <int DIM> constexpr bool kSymDim = DIM >= 2 && DIM <= 6;
 constexpr int kSymMinPoints = 7168;   // below ~7000 points a resident wave gets fewer than 8 tiles and the row-owner sweep is faster (tests/study/symm_crossover.py)
 
 bool sym_eligible(const topolow_session* s) {
-  return s->sym.allowed && s->schedule == TOPOLOW_SCHEDULE_SLAB && s->precision == TOPOLOW_PRECISION_F32 &&
+  return s->sym.allowed && s->schedule == TOPOLOW_SCHEDULE_SLAB &&
+         (s->precision == TOPOLOW_PRECISION_F32 || s->precision == TOPOLOW_PRECISION_F64) &&
          s->row_begin == 0 && s->row_end == s->n && s->n_push == 0 && s->dim >= 2 && s->dim <= 6 && s->n >= s->sym.min_n &&
          s->dim == s->udim;
 }
@@ -746,7 +749,10 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * kSymWaves, 0));
       occ = std::min(occ, std::max(1, per_cu));
     };
-    if (any_thr) {
+    const bool f64 = s->precision == TOPOLOW_PRECISION_F64;
+    if (f64) {
+      if (any_thr) probe(&symm64_sweep_kernel<DIM, true>); else probe(&symm64_sweep_kernel<DIM, false>);
+    } else if (any_thr) {
       probe(&symm_sweep_kernel<DIM, true, false>);
       probe(&symm_sweep_kernel<DIM, true, true>);
     } else {
@@ -774,13 +780,20 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
       hipLaunchKernelGGL(symm_tiles_kernel, dim3(y.tiles), dim3(256), 0, s->stream, y.src_tab.p, y.src_row0.p, (int)src.size(),
                          s->ld, y.tenc.p, TC, t0);
     HIP_TRY(hipGetLastError());
-    constexpr int W = SymRec<DIM>::W;
-    for (auto& r : y.rec) r.alloc((size_t)y.npad * W);
     const int seg_rows = y.seg_last >= y.seg_first ? y.seg_last - y.seg_first + 1 : 1;
-    y.rowpart.alloc((size_t)std::max(y.n_units, 1) * kSymRows * DIM);
-    y.colpart.alloc((size_t)seg_rows * y.npad * DIM);
-    // (a segment's first and last tile-row are partial: the columns its tiles never reach must read as zero)
-    HIP_TRY(hipMemsetAsync(y.colpart.p, 0, (size_t)seg_rows * y.npad * DIM * sizeof(float), s->stream));
+    if (f64) {
+      for (auto& r : y.rec64) r.alloc((size_t)y.npad * SymRec64<DIM>::W);
+      y.rowpart64.alloc((size_t)std::max(y.n_units, 1) * kSymRows * DIM);
+      y.colpart64.alloc((size_t)seg_rows * y.npad * DIM);
+      HIP_TRY(hipMemsetAsync(y.colpart64.p, 0, (size_t)seg_rows * y.npad * DIM * sizeof(double), s->stream));
+    } else {
+      constexpr int W = SymRec<DIM>::W;
+      for (auto& r : y.rec) r.alloc((size_t)y.npad * W);
+      y.rowpart.alloc((size_t)std::max(y.n_units, 1) * kSymRows * DIM);
+      y.colpart.alloc((size_t)seg_rows * y.npad * DIM);
+      // (a segment's first and last tile-row are partial: the columns its tiles never reach must read as zero)
+      HIP_TRY(hipMemsetAsync(y.colpart.p, 0, (size_t)seg_rows * y.npad * DIM * sizeof(float), s->stream));
+    }
     if ((size_t)y.n_units > s->part_sum.n) {   // error partials: one per unit
       HIP_TRY(hipStreamSynchronize(s->stream));
       HIP_TRY(hipStreamSynchronize(s->check_stream));
@@ -808,6 +821,7 @@ bool sym_available(topolow_session* s) {
     (void)hipGetLastError();
     auto& y = s->sym;
     y.tenc.release(); y.rec[0].release(); y.rec[1].release(); y.rowpart.release(); y.colpart.release();
+    y.rec64[0].release(); y.rec64[1].release(); y.rowpart64.release(); y.colpart64.release();
     y.units.release(); y.wave_first.release(); y.row_units.release();
     y.ready = false;
     y.allowed = false;
@@ -826,6 +840,31 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
     auto& y = s->sym;
     ProfScope prof(s, err ? &s->prof_sym_err : &s->prof_sym);
     const int TC = y.npad / kSymCols;
+    if (s->precision == TOPOLOW_PRECISION_F64) {   // relax_symm64.h: same plan, tiles and partial layout, everything else in f64; no fused check
+      if (err) throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep (f64): the check is a separate pass"};
+      if (y.rec_iter != iter) {
+        for (int b = 0; b < 2; ++b)
+          hipLaunchKernelGGL(symm64_records_kernel<DIM>, dim3((y.npad + 255) / 256), dim3(256), 0, s->stream, (const double*)pin,
+                             s->gplus.p, y.rec64[b].p, s->n, y.npad, k, s->c_rep);
+        y.rec_cur = 0;
+      }
+      const double* rec = y.rec64[y.rec_cur].p;
+      double* rec_next = y.rec64[y.rec_cur ^ 1].p;
+      if (s->any_threshold)
+        hipLaunchKernelGGL((symm64_sweep_kernel<DIM, true>), dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec,
+                           y.units.p, y.wave_first.p, y.rowpart64.p, y.colpart64.p, y.npad, s->state.p, 0);
+      else
+        hipLaunchKernelGGL((symm64_sweep_kernel<DIM, false>), dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec,
+                           y.units.p, y.wave_first.p, y.rowpart64.p, y.colpart64.p, y.npad, s->state.p, 0);
+      hipLaunchKernelGGL(symm64_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, s->stream, rec, rec_next, (double*)pout,
+                         s->gplus.p, y.rowpart64.p, y.colpart64.p, y.row_units.p, s->n, y.npad, k * (1.0 - s->cooling), s->c_rep,
+                         iter + 1, s->state.p);
+      HIP_TRY(hipGetLastError());
+      y.rec_cur ^= 1;
+      y.rec_iter = iter + 1;
+      s->stage_launches += 1;
+      return;
+    }
     if (y.rec_iter != iter) {
       for (int b = 0; b < 2; ++b)   // both buffers need the phantom records; the second one's points are overwritten by the apply
         hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((y.npad + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
