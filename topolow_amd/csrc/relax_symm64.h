@@ -9,10 +9,12 @@
 // count of pairs, not bytes.
 //
 // Differences from the fp32 kernel, all consequences of the type: a lane keeps its eight rows (coordinates, two
-// constants, sums: 24 registers per row at ndim 5) in 64-bit pairs, so the kernel is built for ONE wave per SIMD (up
-// to 512 registers per lane); nothing is packed; the column sums of a half tile are reduced over the 8 lanes of a
+// constants: 14 doubles per row at ndim 5) in LDS and only their sums in registers -- 80 of the 254 the ndim-5
+// instance uses, two waves per SIMD (ndim 6: one); nothing is packed; the column sums of a half tile are reduced over the 8 lanes of a
 // column group with three lane exchanges per value (the fp32 kernel's one-instruction DPP adds have no f64 form); the
-// convergence check is not fused (f64 sessions run it as the separate pass they always did).
+// convergence check is NOT fused: the tiles hold the targets as 4-byte words (fp32 rounded to 4 ulp, 3e-7), so an MAE
+// reduced on the way would differ from the reference's edge MAE by 3e-8 -- measured; f64 sessions keep the separate
+// pass over the exact f64 edge list, whose MAE is the reference's to 1e-12 (it runs beside the next sweeps).
 #pragma once
 
 #include "relax_symm.h"
