@@ -3,10 +3,9 @@
 // The same sweep as relax_symm.h -- one-stage iterations, every unordered pair met once from the tile-major copy of the
 // upper triangle, both ends moved, the same plan (units / runs), the same tiles and word order, the same partial
 // buffers and the same fixed-order sum in the apply kernel -- with positions, records, sums and the pair update in
-// f64: distance by IEEE sqrt, the factor by IEEE division (reference src/optimization.cpp:203-281 in double).  Against
-// the row-owner f64 stage kernel it halves the pair evaluations; an f64 pair costs ~65 full-rate f64 instructions
-// (correctly rounded sqrt and division are instruction sequences), so the sweep is VALU-bound and what matters is the
-// count of pairs, not bytes.
+// f64 (reference src/optimization.cpp:203-281 in double; sqrt and reciprocal to 1 ulp, see sym64_pair).  Against the
+// row-owner f64 stage kernel it halves the pair evaluations; an f64 pair costs ~60 full-rate f64 instructions, so the
+// sweep is VALU-bound and what matters is the count of pairs, not bytes.
 //
 // Differences from the fp32 kernel, all consequences of the type: a lane keeps its eight rows (coordinates, two
 // constants: 14 doubles per row at ndim 5) in LDS and only their sums in registers -- 80 of the 254 the ndim-5
@@ -38,12 +37,26 @@ __device__ __forceinline__ void sym64_pair(const double (&pc)[DIM], double ksc, 
     dx[d] = pc[d] - pi[d];
     s = fma(dx[d], dx[d], s);
   }
-#ifdef S64_FAST
-  const double r = __builtin_amdgcn_sqrt(s);
-  const double inv = __builtin_amdgcn_rcp(r + 0.01);
-#else
+#ifdef TOPOLOW_SYM64_IEEE
   const double r = ::sqrt(s);
   const double inv = 1.0 / (r + 0.01);
+#else
+  // sqrt and reciprocal from the hardware estimates (v_rsq_f64, v_rcp_f64: ~2^-26) and two Newton steps each: within
+  // 1 ulp of the correctly rounded results, 15 instructions where the IEEE expansions (scaling for denormals, division
+  // fix-ups) take 25.  s is a sum of squares of coordinate differences: 0 exactly for a point with itself (and then
+  // r = 0), never denormal otherwise; r + 0.01 lies in [0.01, 1e150].
+  const double y0 = __builtin_amdgcn_rsq(s);
+  double g = s * y0, h = 0.5 * y0;
+  double e1 = fma(-h, g, 0.5);
+  g = fma(g, e1, g);
+  h = fma(h, e1, h);
+  const double d1 = fma(-g, g, s);
+  g = fma(d1, h, g);
+  const double r = s > 0.0 ? g : 0.0;
+  const double x = r + 0.01;
+  double inv = __builtin_amdgcn_rcp(x);
+  inv = fma(fma(-x, inv, 1.0), inv, inv);
+  inv = fma(fma(-x, inv, 1.0), inv, inv);
 #endif
   const double t = (double)bits_f32(THR ? (w & ~kCodeMask) : w);
   bool spring;
