@@ -62,8 +62,9 @@ extern "C" {
  *         the oracle's edge error to 2e-5: tests/test_gpu_symmetric.py) and against the row-owner sweep (fp32
  *         summation order only: 2e-6 per iteration, same stop iteration and final MAE to 1e-6 on whole runs);
  *         a row-sharded run shards it over its sessions (same band against one block); f64 sessions take an f64 form
- *         of it (csrc/relax_symm64.h; equal to the f64 CPU model to 1e-12 per iteration, checks stay the exact pass over
- *         the f64 edge list); TOPOLOW_SYMMETRIC=0 / TOPOLOW_SHARD_SYMMETRIC=0 switch it off.
+ *         of it (csrc/relax_symm64.h; equal to the f64 CPU model to 1e-12 per iteration; its fused check is exact --
+ *         the sweep also reads exact-minus-rounded target differences -- and equals the reference's edge MAE to 1e-11);
+ *         TOPOLOW_SYMMETRIC=0 / TOPOLOW_SHARD_SYMMETRIC=0 switch it off.
  * The deterministic pieces -- controller, cooling, error rule, guards, messages -- are exact. */
 
 /* Schedules (topolow_options.schedule). */

@@ -30,6 +30,8 @@ for sym in ("1", "0"):
         wall = time.perf_counter() - t0
         if profile:
             sym_ms, sym_it, _e, _ei = s.profile_symmetric()
+            if _ei:
+                print(f"TOPOLOW_SYMMETRIC={sym}: symmetric iterations that also reduce the check's MAE: {_ei}, {1e3 * _e / _ei:.1f} us each")
             st_ms, st_n, ck_ms, ck_n = s.profile()
             print(f"TOPOLOW_SYMMETRIC={sym}: symmetric {sym_it} iterations {1e3 * sym_ms / max(sym_it, 1):.1f} us each; "
                   f"stage launches {st_n} {1e3 * st_ms / max(st_n, 1):.1f} us each; checks {ck_n} {1e3 * ck_ms / max(ck_n, 1):.1f} us each")

@@ -56,8 +56,8 @@ struct SymUnit {
 // then "its second", which for odd a are columns 2h + 1 and 2h, so that the first step of the column reduction --
 // between the lanes a and a ^ 1 -- can add the one's first to the other's second with one instruction per
 // coordinate (sym_col_reduce).  Each load of the wave covers 1 KB.
-inline long long sym_tile_index(int R, int J, int TC) { return (long long)R * TC - (long long)R * (R - 1) + (J - 2 * R); }
-inline size_t sym_word_in_tile(int r, int c) {   // r in [0, 64), c in [0, 32)
+TL_HD inline long long sym_tile_index(int R, int J, int TC) { return (long long)R * TC - (long long)R * (R - 1) + (J - 2 * R); }
+TL_HD inline size_t sym_word_in_tile(int r, int c) {   // r in [0, 64), c in [0, 32)
   const int a = r >> 3, p = (r & 7) >> 1, e = r & 1, b = c >> 2, h = (c & 3) >> 1, f = c & 1;
   return (size_t)((((4 * h + p) * 64) + a + 8 * b) * 4 + 2 * (f ^ (a & 1)) + e);
 }

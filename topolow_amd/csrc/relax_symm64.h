@@ -10,10 +10,14 @@
 // Differences from the fp32 kernel, all consequences of the type: a lane keeps its eight rows (coordinates, two
 // constants: 14 doubles per row at ndim 5) in LDS and only their sums in registers -- 80 of the 254 the ndim-5
 // instance uses, two waves per SIMD (ndim 6: one); nothing is packed; the column sums of a half tile are reduced over the 8 lanes of a
-// column group with three lane exchanges per value (the fp32 kernel's one-instruction DPP adds have no f64 form); the
-// convergence check is NOT fused: the tiles hold the targets as 4-byte words (fp32 rounded to 4 ulp, 3e-7), so an MAE
-// reduced on the way would differ from the reference's edge MAE by 3e-8 -- measured; f64 sessions keep the separate
-// pass over the exact f64 edge list, whose MAE is the reference's to 1e-12 (it runs beside the next sweeps).
+// column group with three lane exchanges per value (the fp32 kernel's one-instruction DPP adds have no f64 form).
+//
+// The fused convergence check (ERR instance) is EXACT.  The tiles hold the targets as 4-byte words (fp32 rounded to
+// 4 ulp, 3e-7 relative): reduced from them the MAE would sit 3e-8 off the reference's edge MAE (measured), where the
+// separate pass of f64 sessions over the f64 edge list is exact.  So the ERR instance also reads, tile-major like the
+// words, what the rounding took away: delta = (exact f64 target) - (decoded word), stored as fp32 (symm64_delta_kernel,
+// from the session's f64 edge list; 6e-8 of 3e-7 of the target: 2e-14 relative), and sums |t_word + delta - r| = the
+// exact |t - r|.  Forces still come from the words, as in every other f64 kernel of the library.
 #pragma once
 
 #include "relax_symm.h"
@@ -27,9 +31,10 @@ __device__ __forceinline__ double sym64_xor(double v, int mask) { return __shfl_
 
 // one row x one column: both halves of the pair.  base = (t - r) / (r + 0.01) for a spring, 1 / (r + 0.01)^3 otherwise;
 // every endpoint multiplies it with its own constant of that kind.
-template <int DIM, bool THR>
+template <int DIM, bool THR, bool ERR>
 __device__ __forceinline__ void sym64_pair(const double (&pc)[DIM], double ksc, double cgc, const double (&pi)[DIM],
-                                           double ksr, double cgr, uint32_t w, double (&racc)[DIM], double (&cacc)[DIM]) {
+                                           double ksr, double cgr, uint32_t w, double (&racc)[DIM], double (&cacc)[DIM],
+                                           uint32_t dl_bits, double& err, unsigned& cnt) {
   double dx[DIM];
   double s = 0.0;
 #pragma unroll
@@ -78,15 +83,43 @@ __device__ __forceinline__ void sym64_pair(const double (&pc)[DIM], double ksc, 
     racc[d] = fma(dx[d], coef, racc[d]);
     cacc[d] = fma(dx[d], cc, cacc[d]);
   }
+  if constexpr (ERR) {   // the convergence MAE of the positions this sweep reads, against the EXACT target t + delta
+    err += spring ? fabs((t - r) + (double)bits_f32(dl_bits)) : 0.0;
+    if constexpr (THR) cnt += spring ? 1u : 0u;
+  }
+}
+
+// delta tiles: for every edge of the session's f64 edge list (session labels; codes 0, 1, -1) the difference between the
+// exact target and what its 4-byte word decodes to, at the cell(s) of the tile-major copy the sweep meets the pair at
+// (a pair inside a diagonal square is met from both sides).  tdelta: zero-filled by the caller.
+__global__ __launch_bounds__(256) void symm64_delta_kernel(const int* __restrict__ ei, const int* __restrict__ ej,
+                                                          const double* __restrict__ et, const int8_t* __restrict__ ec,
+                                                          long long n_edges, float* __restrict__ tdelta, int TC, int n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (long long)gridDim.x * blockDim.x) {
+    const int a = ei[e], b = ej[e], c = ec[e];
+    if (a < 0 || b < 0 || a >= n || b >= n || a == b || c == 2) continue;
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const double t = et[e];
+    const uint32_t w = encode_target(t, c);
+    if (w == kInfWord) continue;
+    const float dl = (float)(t - (double)bits_f32(w & ~kCodeMask));
+    const int R = lo / kSymRows;
+    tdelta[(size_t)sym_tile_index(R, hi / kSymCols, TC) * kSymTileWords + sym_word_in_tile(lo % kSymRows, hi % kSymCols)] = dl;
+    if (hi / kSymRows == R)
+      tdelta[(size_t)sym_tile_index(R, lo / kSymCols, TC) * kSymTileWords + sym_word_in_tile(hi % kSymRows, lo % kSymCols)] = dl;
+  }
 }
 
 // enc, units, runs, col_row0: as symm_sweep_kernel.  rec: npad records of SymRec64<DIM>::W doubles.
-// rowpart [n_units][64][DIM], colpart [n_tile_rows][npad][DIM] in f64.
-template <int DIM, bool ANYTHR>
-__global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_sweep_kernel(
+// rowpart [n_units][64][DIM], colpart [n_tile_rows][npad][DIM] in f64.  ERR: tdelta (tile-major like enc, see above);
+// part_sum / part_cnt / fixed_cnt as symm_sweep_kernel leaves them (TWICE the sum and the count over the unit's
+// contributing pairs; a pair of the diagonal square is met from both sides and counts once per visit).
+template <int DIM, bool ANYTHR, bool ERR>
+__global__ __launch_bounds__(64 * kSymWaves, ((DIM <= 3 || (DIM == 4 && !(ANYTHR && ERR)) || (DIM == 5 && !ERR)) ? 2 : 1)) void symm64_sweep_kernel(
     const uint32_t* __restrict__ enc, const double* __restrict__ rec, const SymUnit* __restrict__ units,
     const SymRun* __restrict__ runs, double* __restrict__ rowpart, double* __restrict__ colpart, int npad,
-    const RunState* st, int col_row0) {
+    const RunState* st, int col_row0, const float* __restrict__ tdelta, double* __restrict__ part_sum,
+    unsigned long long* __restrict__ part_cnt, unsigned long long fixed_cnt) {
   if (st != nullptr && st->stopped) return;
   constexpr int W = SymRec64<DIM>::W;
   constexpr int kRecVec = W / 2;                   // 16-byte pieces per record
@@ -116,6 +149,8 @@ __global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_swe
     // in registers, eight rows' coordinates and constants cost 112 of them and the kernel spilled); only the row sums
     // stay in registers.  Record r sits one 16-byte piece further for every 8 rows, so the 8 lane groups a read 8 banks
     double racc[8][DIM];
+    double err_tile = 0.0, err_unit = 0.0;
+    unsigned cnt_tile = 0, cnt_unit2 = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -133,8 +168,19 @@ __global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_swe
       for (int p = 0; p < 4; ++p)
         dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + ((J - J0) * 8 + 4 * h + p) * 1024, 0, 0);
     };
-    u32x4 wa[4], wb[4];
+    // the ERR instance's delta words: the same addresses in the tile-major delta array
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ERR ? tdelta + (size_t)tile0 * kSymTileWords : nullptr), 0, ERR ? (J1 - J0) * kSymTileWords * 4 : 0, 0x00020000);
+    auto request_delta = [&](int J, int h, u32x4 (&dst)[4]) {
+      if constexpr (ERR) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          dst[p] = __builtin_amdgcn_raw_buffer_load_b128(drsrc, lane * 16 + ((J - J0) * 8 + 4 * h + p) * 1024, 0, 0);
+      }
+    };
+    u32x4 wa[4], wb[4], da[4], db[4];
     request(J0, 0, wa);
+    request_delta(J0, 0, da);
     const uint4* recv = reinterpret_cast<const uint4*>(rec);
     if (lane < kTileVec) lds[wave][J0 & 1][lane] = recv[(size_t)J0 * kTileVec + lane];
     if constexpr (kTileVec > 64) if (lane + 64 < kTileVec) lds[wave][J0 & 1][lane + 64] = recv[(size_t)J0 * kTileVec + lane + 64];
@@ -145,11 +191,12 @@ __global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_swe
     for (int J = J0; J < J1; ++J) {
       const int Jn = J + 1 < J1 ? J + 1 : J;
       request(J, 1, wb);
+      request_delta(J, 1, db);
       u32x4 rn0 = {0, 0, 0, 0}, rn1 = {0, 0, 0, 0};
       rn0 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (Jn * kTileVec + lane) * 16, 0, 0);
       if constexpr (kTileVec > 64) rn1 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (Jn * kTileVec + lane + 64) * 16, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      auto half = [&](auto hc, const u32x4 (&wc)[4]) {   // columns 2h, 2h + 1 of the lane's four x its eight rows
+      auto half = [&](auto hc, const u32x4 (&wc)[4], const u32x4 (&dc)[4]) {   // columns 2h, 2h + 1 of the lane's four x its eight rows
         constexpr int h = decltype(hc)::value;
         double cacc[2][DIM], pc[2][DIM], ksc[2], cgc[2];
 #pragma unroll
@@ -180,8 +227,9 @@ __global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_swe
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const uint32_t w0 = c == 0 ? wc[p].x : wc[p].z, w1 = c == 0 ? wc[p].y : wc[p].w;
-            sym64_pair<DIM, ANYTHR>(pc[c], ksc[c], cgc[c], pi[0], ks[0], cg[0], w0, racc[2 * p], cacc[c]);
-            sym64_pair<DIM, ANYTHR>(pc[c], ksc[c], cgc[c], pi[1], ks[1], cg[1], w1, racc[2 * p + 1], cacc[c]);
+            const uint32_t d0 = ERR ? (c == 0 ? dc[p].x : dc[p].z) : 0u, d1 = ERR ? (c == 0 ? dc[p].y : dc[p].w) : 0u;
+            sym64_pair<DIM, ANYTHR, ERR>(pc[c], ksc[c], cgc[c], pi[0], ks[0], cg[0], w0, racc[2 * p], cacc[c], d0, err_tile, cnt_tile);
+            sym64_pair<DIM, ANYTHR, ERR>(pc[c], ksc[c], cgc[c], pi[1], ks[1], cg[1], w1, racc[2 * p + 1], cacc[c], d1, err_tile, cnt_tile);
           }
           // four pairs in flight, no more.  The sums are pinned here (empty statements that "use" them): a scheduling
           // barrier alone does not order pure arithmetic -- instruction selection had put every pair's distance and factor
@@ -190,6 +238,7 @@ __global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_swe
 #pragma unroll
           for (int d = 0; d < DIM; ++d)
             asm volatile("" : "+v"(racc[2 * p][d]), "+v"(racc[2 * p + 1][d]), "+v"(cacc[0][d]), "+v"(cacc[1][d]));
+          if constexpr (ERR) asm volatile("" : "+v"(err_tile));
           __builtin_amdgcn_sched_barrier(0);
         }
         // column sums over the 8 lanes a = 0..7 of the column group: lanes a and a ^ 1 hold the two columns in opposite
@@ -218,10 +267,18 @@ __global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_swe
           }
         }
       };
-      half(std::integral_constant<int, 0>{}, wa);
+      half(std::integral_constant<int, 0>{}, wa, da);
       request(Jn, 0, wa);                  // the next tile's first half, while this tile's second half is computed
+      request_delta(Jn, 0, da);
       __builtin_amdgcn_sched_barrier(0);
-      half(std::integral_constant<int, 1>{}, wb);
+      half(std::integral_constant<int, 1>{}, wb, db);
+      if constexpr (ERR) {
+        const bool diag = J < 2 * R + 2;
+        err_unit += diag ? err_tile : 2.0 * err_tile;
+        cnt_unit2 += diag ? cnt_tile : 2u * cnt_tile;
+        err_tile = 0.0;
+        cnt_tile = 0;
+      }
       __builtin_amdgcn_sched_barrier(0);
       lds[wave][(J + 1) & 1][lane] = make_uint4(rn0.x, rn0.y, rn0.z, rn0.w);
       if constexpr (kTileVec > 64) lds[wave][(J + 1) & 1][lane + 64] = make_uint4(rn1.x, rn1.y, rn1.z, rn1.w);   // (slots >= kTileVec: never read)
@@ -243,6 +300,19 @@ __global__ __launch_bounds__(64 * kSymWaves, (DIM <= 5 ? 2 : 1)) void symm64_swe
       for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int d = 0; d < DIM; ++d) dst[q * DIM + d] = racc[q][d];
+    }
+    if constexpr (ERR) {
+      double es = err_unit;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) es += sym64_xor(es, m);
+      if constexpr (ANYTHR) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) cnt_unit2 += __shfl_xor(cnt_unit2, m, 64);
+      }
+      if (lane == 0) {
+        part_sum[u] = es;
+        part_cnt[u] = ANYTHR ? (unsigned long long)cnt_unit2 : (u == 0 ? fixed_cnt : 0ull);
+      }
     }
   }
 }

@@ -235,6 +235,7 @@ struct topolow_session {
   long long n_edges = 0;
   int n_parts = 0;
   bool dense_mae = false;   // edge list verified == measured cells of the encoded block
+  bool list_is_block = false;   // ... the verification itself (dense_mae also wants fp32 and ndim <= 16)
   bool dense_parity = false;
   int dense_blocks = 0, dense_grid_x = 0, dense_grid_y = 0;
   DevBuf<double> part_sum;
@@ -278,6 +279,8 @@ struct topolow_session {
     int rec_cur = 0, rec_iter = -1;   // rec[rec_cur] holds the records of iteration rec_iter
     DevBuf<float> rowpart, colpart;
     DevBuf<double> rec64[2], rowpart64, colpart64;   // f64 sessions (relax_symm64.h)
+    DevBuf<float> tdelta;          // ... exact target - decoded word per cell of tenc: the fused check's MAE is exact
+    bool delta_ready = false;
     DevBuf<SymUnit> units;
     DevBuf<SymRun> wave_first;     // per wave of the grid: its run of units (relax_symm.h: SymPlan::runs)
     DevBuf<int2> row_units;
@@ -751,7 +754,8 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
     };
     const bool f64 = s->precision == TOPOLOW_PRECISION_F64;
     if (f64) {
-      if (any_thr) probe(&symm64_sweep_kernel<DIM, true>); else probe(&symm64_sweep_kernel<DIM, false>);
+      if (any_thr) { probe(&symm64_sweep_kernel<DIM, true, false>); probe(&symm64_sweep_kernel<DIM, true, true>); }
+      else { probe(&symm64_sweep_kernel<DIM, false, false>); probe(&symm64_sweep_kernel<DIM, false, true>); }
     } else if (any_thr) {
       probe(&symm_sweep_kernel<DIM, true, false>);
       probe(&symm_sweep_kernel<DIM, true, true>);
@@ -786,6 +790,16 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
       y.rowpart64.alloc((size_t)std::max(y.n_units, 1) * kSymRows * DIM);
       y.colpart64.alloc((size_t)seg_rows * y.npad * DIM);
       HIP_TRY(hipMemsetAsync(y.colpart64.p, 0, (size_t)seg_rows * y.npad * DIM * sizeof(double), s->stream));
+      // the fused check needs the edge list to BE the block's measured cells and to be on the device in f64
+      y.delta_ready = false;
+      if (s->list_is_block && !s->dense_mae && s->n_edges > 0 && t0 == 0 && (long long)y.tiles == (long long)TR * (TR + 1)) {
+        y.tdelta.alloc((size_t)y.tiles * kSymTileWords);
+        HIP_TRY(hipMemsetAsync(y.tdelta.p, 0, (size_t)y.tiles * kSymTileWords * sizeof(float), s->stream));
+        hipLaunchKernelGGL(symm64_delta_kernel, dim3(2048), dim3(256), 0, s->stream, s->ei.p, s->ej.p, (const double*)s->et.p,
+                           s->ec.p, (long long)s->n_edges, y.tdelta.p, TC, s->n);
+        HIP_TRY(hipGetLastError());
+        y.delta_ready = true;
+      }
     } else {
       constexpr int W = SymRec<DIM>::W;
       for (auto& r : y.rec) r.alloc((size_t)y.npad * W);
@@ -821,7 +835,8 @@ bool sym_available(topolow_session* s) {
     (void)hipGetLastError();
     auto& y = s->sym;
     y.tenc.release(); y.rec[0].release(); y.rec[1].release(); y.rowpart.release(); y.colpart.release();
-    y.rec64[0].release(); y.rec64[1].release(); y.rowpart64.release(); y.colpart64.release();
+    y.rec64[0].release(); y.rec64[1].release(); y.rowpart64.release(); y.colpart64.release(); y.tdelta.release();
+    y.delta_ready = false;
     y.units.release(); y.wave_first.release(); y.row_units.release();
     y.ready = false;
     y.allowed = false;
@@ -840,8 +855,8 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
     auto& y = s->sym;
     ProfScope prof(s, err ? &s->prof_sym_err : &s->prof_sym);
     const int TC = y.npad / kSymCols;
-    if (s->precision == TOPOLOW_PRECISION_F64) {   // relax_symm64.h: same plan, tiles and partial layout, everything else in f64; no fused check
-      if (err) throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep (f64): the check is a separate pass"};
+    if (s->precision == TOPOLOW_PRECISION_F64) {   // relax_symm64.h: same plan, tiles and partial layout, everything else in f64
+      if (err && !y.delta_ready) throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep (f64): no delta tiles for a fused check"};
       if (y.rec_iter != iter) {
         for (int b = 0; b < 2; ++b)
           hipLaunchKernelGGL(symm64_records_kernel<DIM>, dim3((y.npad + 255) / 256), dim3(256), 0, s->stream, (const double*)pin,
@@ -850,18 +865,23 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
       }
       const double* rec = y.rec64[y.rec_cur].p;
       double* rec_next = y.rec64[y.rec_cur ^ 1].p;
-      if (s->any_threshold)
-        hipLaunchKernelGGL((symm64_sweep_kernel<DIM, true>), dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec,
-                           y.units.p, y.wave_first.p, y.rowpart64.p, y.colpart64.p, y.npad, s->state.p, 0);
-      else
-        hipLaunchKernelGGL((symm64_sweep_kernel<DIM, false>), dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec,
-                           y.units.p, y.wave_first.p, y.rowpart64.p, y.colpart64.p, y.npad, s->state.p, 0);
+      auto sweep64 = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec, y.units.p, y.wave_first.p,
+                           y.rowpart64.p, y.colpart64.p, y.npad, s->state.p, 0, y.tdelta.p, s->part_sum.p, s->part_cnt.p,
+                           s->block_cells);
+      };
+      if (s->any_threshold) {
+        if (err) sweep64(&symm64_sweep_kernel<DIM, true, true>); else sweep64(&symm64_sweep_kernel<DIM, true, false>);
+      } else {
+        if (err) sweep64(&symm64_sweep_kernel<DIM, false, true>); else sweep64(&symm64_sweep_kernel<DIM, false, false>);
+      }
       hipLaunchKernelGGL(symm64_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, s->stream, rec, rec_next, (double*)pout,
                          s->gplus.p, y.rowpart64.p, y.colpart64.p, y.row_units.p, s->n, y.npad, k * (1.0 - s->cooling), s->c_rep,
                          iter + 1, s->state.p);
       HIP_TRY(hipGetLastError());
       y.rec_cur ^= 1;
       y.rec_iter = iter + 1;
+      if (err) s->fused_parts = y.n_units;
       s->stage_launches += 1;
       return;
     }
@@ -1398,7 +1418,8 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
     s->dense_parity = !(s->row_begin == 0 && s->row_end == s->n);
     const int* inv = s->inv.empty() ? nullptr : s->inv.data();
     const char* force = getenv("TOPOLOW_EDGE_MAE");
-    if (s->gplus.p && !(force && atoi(force) != 0) && s->precision == TOPOLOW_PRECISION_F32) {
+    s->list_is_block = false;
+    if (s->gplus.p && !(force && atoi(force) != 0)) {
       std::atomic<bool> owned{true};
       std::atomic<unsigned long long> fp_total{0};
       host_parallel(m, [&](size_t lo_e, size_t hi_e) {
@@ -1429,7 +1450,10 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
         HIP_TRY(hipStreamSynchronize(s->stream));
         unsigned long long h[2];
         HIP_TRY(hipMemcpy(h, d_fp.p, 16, hipMemcpyDeviceToHost));
-        s->dense_mae = (h[0] == fp_total.load()) && (h[1] == (unsigned long long)m) && s->dim <= kMaxTunedDim;
+        s->list_is_block = (h[0] == fp_total.load()) && (h[1] == (unsigned long long)m);
+        // (f64 sessions keep the exact edge-list pass: the block holds 4-byte targets; their symmetric sweep fuses the
+        //  check through the delta tiles instead, relax_symm64.h)
+        s->dense_mae = s->list_is_block && s->dim <= kMaxTunedDim && s->precision == TOPOLOW_PRECISION_F32;
       }
     }
     if (s->dense_mae) {   // the gather fallback is not needed: keep 1-element placeholders
@@ -1569,7 +1593,8 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         const bool sym = g.n_stages == 1 && sym_eligible(s) && sym_available(s);
         // (the row-owner ERR instance pairs rows two by two: an odd block keeps the separate pass; the symmetric
         //  sweep's ERR instance has no such rule)
-        const bool fuse_now = s->pcheck.active && g.n_stages == 1 && (sym || s->rows() % 2 == 0);
+        const bool fuse_now = s->pcheck.active && g.n_stages == 1 &&
+                              (s->precision == TOPOLOW_PRECISION_F64 ? (sym && s->sym.delta_ready) : (sym || s->rows() % 2 == 0));
         if (s->pcheck.active && !fuse_now) flush_pending_check(s);
         if (sym) {   // one sweep over the upper triangle moves both ends of every pair
           int out = 0;
@@ -1607,9 +1632,10 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         s->held = pc.beside ? s->cur : -1;
         // one stage next iteration: its kernel reduces this check's MAE (the positions it reads ARE this
         // check's positions) and the separate pass over the block is dropped
+        // (fp32: the row-owner ERR instance or the symmetric sweep's; f64: the symmetric sweep's, exact through its delta tiles)
         const bool fuse = s->fuse_checks && s->schedule == TOPOLOW_SCHEDULE_SLAB && iter + 1 < s->n_iter &&
-                          s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 &&
-                          (s->rows() % 2 == 0 || sym_eligible(s)) &&
+                          ((s->dense_mae && s->precision == TOPOLOW_PRECISION_F32 && (s->rows() % 2 == 0 || sym_eligible(s))) ||
+                           (s->precision == TOPOLOW_PRECISION_F64 && sym_eligible(s) && sym_available(s) && s->sym.delta_ready)) &&
                           slab_geom(s->n, s->fixed_stages > 0 ? s->fixed_stages
                                                               : slab_stages_at(iter + 1, s->k_host, s->dim)).n_stages == 1;
         if (fuse) s->pcheck = pc;
