@@ -318,3 +318,31 @@ def test_symmetric_sweep_f64_whole_run_at_config3_generator_size():
     assert a.final_mae == pytest.approx(b.final_mae, rel=1e-6)
     sm, cnt = orc.edge_error(a.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
     assert a.final_mae == pytest.approx(sm / cnt, rel=1e-12)
+
+
+def test_symmetric_sweep_f64_check_falls_back_when_the_edge_list_is_not_the_block():
+    """The fused f64 check sums over the measured cells of the tiles, so it may only replace the pass over the edge list
+    when that list IS the block's measured upper triangle (verified by fingerprint when the list is set).  A session
+    given half of the edges keeps the separate pass (no ERR launches) and reports the MAE of exactly those edges; with
+    random labels and the full list the fused check is used and is exact."""
+    n, dim, k0 = 1000, 5, 1.5
+    call, _ = pp.random_problem(n, dim, 0.7, seed=77, n_iter=7, k0=k0)
+    call = _with_thresholds(call, 0.1)
+    call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
+    want = _model_iterations(call_r, 7, k0, 0.01, 0.01)
+    half = np.arange(call.edge_i.shape[0]) % 2 == 0
+    part = dataclasses.replace(call, edge_i=call.edge_i[half], edge_j=call.edge_j[half], edge_dist=call.edge_dist[half],
+                               edge_thresh=call.edge_thresh[half])
+    got, trace, counts = _symmetric_session(part, n, dim, 7, k0, 0.01, 0.01, 3, profile=True, precision="f64")
+    assert counts[1] == 7 and counts[3] == 0
+    scale = np.abs(want[-1] - call.initial_positions).max()
+    assert np.abs(got - want[-1]).max() <= 1e-12 * scale * 7
+    for row in trace:
+        sm, c = orc.edge_error(want[int(row[0]) - 1], part.edge_i, part.edge_j, part.edge_dist, part.edge_thresh)
+        assert row[1] == pytest.approx(sm / c, rel=1e-11)
+    got2, trace2, counts2 = _symmetric_session(call, n, dim, 7, k0, 0.01, 0.01, 3, profile=True, relabel=91, precision="f64")
+    assert counts2[1] == 5 and counts2[3] == 2
+    assert np.abs(got2 - want[-1]).max() <= 1e-12 * scale * 7
+    for row in trace2:
+        sm, c = orc.edge_error(want[int(row[0]) - 1], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        assert row[1] == pytest.approx(sm / c, rel=1e-11)
