@@ -46,8 +46,30 @@ template <> struct Math<float> {
   static constexpr float far() { return kFarF32; }
 };
 template <> struct Math<double> {
+  // The hardware estimates (v_rsq_f64, v_rcp_f64: ~2^-26) and two Newton steps: within 1 ulp of the correctly rounded
+  // result, 15 instructions for the pair where the IEEE expansions (scaling for denormals, division fix-ups) take 25.
+  // The arguments here are sums of squares of coordinate differences -- exactly 0 for a point with itself, never
+  // denormal otherwise -- and r + 0.01 in [0.01, 1e150].  (-DTOPOLOW_F64_IEEE: the library calls.)  The exact GS
+  // kernels (relax_gs.h, relax_tilegs.h), which are held to the CPU oracle pair by pair, do not come through here.
+#ifdef TOPOLOW_F64_IEEE
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+#else
+  static __device__ __forceinline__ double sqrt(double x) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0, h = 0.5 * y0;
+    const double e1 = fma(-h, g, 0.5);
+    g = fma(g, e1, g);
+    h = fma(h, e1, h);
+    g = fma(fma(-g, g, x), h, g);
+    return x > 0.0 ? g : 0.0;
+  }
+  static __device__ __forceinline__ double rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+  }
+#endif
   static constexpr double far() { return kFarF64; }
 };
 

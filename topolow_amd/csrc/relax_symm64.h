@@ -20,6 +20,7 @@
 // exact |t - r|.  Forces still come from the words, as in every other f64 kernel of the library.
 #pragma once
 
+#include "relax_kernels.h"
 #include "relax_symm.h"
 
 namespace topolow {
@@ -42,27 +43,8 @@ __device__ __forceinline__ void sym64_pair(const double (&pc)[DIM], double ksc, 
     dx[d] = pc[d] - pi[d];
     s = fma(dx[d], dx[d], s);
   }
-#ifdef TOPOLOW_SYM64_IEEE
-  const double r = ::sqrt(s);
-  const double inv = 1.0 / (r + 0.01);
-#else
-  // sqrt and reciprocal from the hardware estimates (v_rsq_f64, v_rcp_f64: ~2^-26) and two Newton steps each: within
-  // 1 ulp of the correctly rounded results, 15 instructions where the IEEE expansions (scaling for denormals, division
-  // fix-ups) take 25.  s is a sum of squares of coordinate differences: 0 exactly for a point with itself (and then
-  // r = 0), never denormal otherwise; r + 0.01 lies in [0.01, 1e150].
-  const double y0 = __builtin_amdgcn_rsq(s);
-  double g = s * y0, h = 0.5 * y0;
-  double e1 = fma(-h, g, 0.5);
-  g = fma(g, e1, g);
-  h = fma(h, e1, h);
-  const double d1 = fma(-g, g, s);
-  g = fma(d1, h, g);
-  const double r = s > 0.0 ? g : 0.0;
-  const double x = r + 0.01;
-  double inv = __builtin_amdgcn_rcp(x);
-  inv = fma(fma(-x, inv, 1.0), inv, inv);
-  inv = fma(fma(-x, inv, 1.0), inv, inv);
-#endif
+  const double r = Math<double>::sqrt(s);             // 1 ulp (relax_kernels.h): estimate + two Newton steps
+  const double inv = Math<double>::rcp(r + 0.01);
   const double t = (double)bits_f32(THR ? (w & ~kCodeMask) : w);
   bool spring;
   if constexpr (THR) {
