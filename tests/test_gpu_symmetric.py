@@ -346,3 +346,20 @@ def test_symmetric_sweep_f64_check_falls_back_when_the_edge_list_is_not_the_bloc
     for row in trace2:
         sm, c = orc.edge_error(want[int(row[0]) - 1], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
         assert row[1] == pytest.approx(sm / c, rel=1e-11)
+    # the same session given another edge list afterwards: its delta tiles are rebuilt (or dropped), never reused
+    with _Env(TOPOLOW_SYMMETRIC="1", TOPOLOW_SYMMETRIC_MIN_N="0"):
+        ses = _native.Session(n, dim, precision="f64")
+    ses.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
+    for edges, fused in ((call, 2), (part, 0), (call, 2)):
+        ses.set_edges(edges.edge_i, edges.edge_j, edges.edge_dist, edges.edge_thresh)
+        ses.set_positions(call.initial_positions)
+        ses.set_profiling(True)
+        ses.begin(7, k0, 0.01, 0.01, 1e-12, 10 ** 9, 3, 5, 1)
+        ses.run()
+        ses.sync()
+        assert ses.profile_symmetric()[3] == fused
+        for row in ses.check_trace():
+            sm, c = orc.edge_error(want[int(row[0]) - 1], edges.edge_i, edges.edge_j, edges.edge_dist, edges.edge_thresh)
+            assert row[1] == pytest.approx(sm / c, rel=1e-11)
+        ses.set_profiling(False)
+    ses.close()

@@ -1398,6 +1398,10 @@ int topolow_session_set_edges(topolow_session* s, const int32_t* edge_i, const i
   return guarded(errbuf, errlen, [&] {
     HIP_TRY(hipSetDevice(s->device));
     s->n_edges = n_edges;
+    if (s->precision == TOPOLOW_PRECISION_F64) {   // the f64 sweep's delta tiles are made from this list: rebuilt on first use
+      s->sym.ready = false;
+      s->sym.delta_ready = false;
+    }
     const size_t m = (size_t)n_edges;
     long long blocks = (n_edges + (long long)kThreads * 8 - 1) / ((long long)kThreads * 8);
     if (blocks < 1) blocks = 1;
