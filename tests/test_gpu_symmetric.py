@@ -363,3 +363,43 @@ def test_symmetric_sweep_f64_check_falls_back_when_the_edge_list_is_not_the_bloc
             assert row[1] == pytest.approx(sm / c, rel=1e-11)
         ses.set_profiling(False)
     ses.close()
+
+
+def test_symmetric_sweep_f64_fuzz_through_the_production_entry():
+    """Ragged sizes (n not a multiple of 8, 32 or 64; fewer tile-rows than waves), 2..6 coordinates, thresholds, every
+    check cadence, the size gate at zero, random labels (the production entry relabels): whole f64 runs with the
+    symmetric sweep against the same runs on the row-owner f64 kernel -- same schedule and arithmetic, the sums grouped
+    differently, the checks fused (exact through the delta tiles) against separate: positions to 1e-9 of the
+    coordinate scale, the same verdict, the final MAE to 1e-10 and equal to the oracle's edge error of the returned
+    positions to 1e-11."""
+    rng = np.random.default_rng(4711)
+    done = 0
+    for case in range(10):
+        n = int(rng.integers(130, 900))
+        dim = int(rng.choice([2, 3, 4, 5, 6]))
+        call, _ = pp.random_problem(n, dim, float(rng.choice([0.3, 0.7, 0.9])), seed=2000 + case,
+                                    thresholds=float(rng.choice([0.0, 0.2])), n_iter=int(rng.integers(12, 60)),
+                                    k0=float(rng.uniform(0.5, 6.0)), cool=0.02, c_rep=0.01, check_freq=int(rng.integers(1, 5)),
+                                    window=3, eps=1e-6)
+        seed = int(rng.integers(1, 2 ** 62))
+        runs = {}
+        for sym in ("1", "0"):
+            with _Env(TOPOLOW_SYMMETRIC=sym, TOPOLOW_SYMMETRIC_MIN_N="0"):
+                try:
+                    runs[sym] = _native.optimize_layout_exact_arrays(*layout_call_args(call), seed=seed, schedule="slab",
+                                                                    precision="f64")
+                except _native.NativeError as e:
+                    runs[sym] = str(e)
+        a, b = runs["1"], runs["0"]
+        if isinstance(a, str) or isinstance(b, str):
+            assert a == b
+            continue
+        scale = max(1.0, float(np.abs(b.positions).max()))
+        assert np.abs(a.positions - b.positions).max() <= 1e-9 * scale, (n, dim)
+        assert (a.converged, a.iterations) == (b.converged, b.iterations)
+        assert a.final_mae == pytest.approx(b.final_mae, rel=1e-10, abs=1e-14)
+        sm, cnt = orc.edge_error(a.positions, call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
+        if cnt > 0:
+            assert a.final_mae == pytest.approx(sm / cnt, rel=1e-11, abs=1e-14)
+        done += 1
+    assert done >= 7
