@@ -33,7 +33,8 @@ def _problem(dim, thr):
 
 def _rank_main(rank, world, port, q, dim, thr, symmetric):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      TOPOLOW_SYMMETRIC="1", TOPOLOW_SYMMETRIC_MIN_N="0")
+                      TOPOLOW_SYMMETRIC="1", TOPOLOW_SYMMETRIC_MIN_N="0",
+                      TOPOLOW_SEGMENT_PIECE_ROWS="100" if dim == 5 else "0")     # the row slices travel in several messages
     import faulthandler
     faulthandler.dump_traceback_later(240, exit=True)     # a rank that hangs says where, and the parent sees it die
     import torch

@@ -245,6 +245,8 @@ class HipBackend:
         coll.all_reduce_tensor(vote)
         if vote.item() < world:
             return False
+        # rows per message: at most 1 GB (element counts stay far inside 32 bits); tests make the pieces small
+        piece = int(os.environ.get("TOPOLOW_SEGMENT_PIECE_ROWS", 0)) or max(1, (1 << 28) // ld)
         for dst in range(world):            # the same order on every rank: a transfer at a time, no cycle to wait in
             nf, ne = needs[dst]
             for src in range(world):
@@ -255,8 +257,10 @@ class HipBackend:
                     if rank == dst:
                         stage[lo - nf:hi - nf] = enc[lo - b:hi - b]
                 elif rank in (src, dst):
-                    coll.move_rows(src, dst, rank, send=enc[lo - b:hi - b] if rank == src else None,
-                                   recv=stage[lo - nf:hi - nf] if rank == dst else None)
+                    for r0 in range(lo, hi, piece):
+                        r1 = min(hi, r0 + piece)
+                        coll.move_rows(src, dst, rank, send=enc[r0 - b:r1 - b] if rank == src else None,
+                                       recv=stage[r0 - nf:r1 - nf] if rank == dst else None)
         ok = 1.0
         try:
             s.symm_segment_build(rank, world, stage.data_ptr(), first, end - first, any_thr)
