@@ -219,9 +219,13 @@ def run_single(args):
                                              "2 N^2-byte pass); check_us is then the controller alone"),
         "stage_kernel": priced(stage_ms - fused_ms, plain_launches, bytes_iter * (n_timed - sym_iters - sym_err_iters
                                                                                   - fused_launches),
-                               "slab_stage_pipe_kernel<5,float>",
-                               "row-owner launches: 1/16 of the columns while the layout unfolds, 1/2 while k > 3 "
-                               "(and whole-matrix ones where the symmetric sweep does not apply)"),
+                               "slab_stage_pipe_kernel<5,float> (16-stage iterations) + symm_sweep_kernel<5> / "
+                               "symm_apply_kernel<5> on half the tiles (two-stage iterations)",
+                               "the stages of multi-stage iterations: row-owner launches over 1/16 of the columns while "
+                               "the layout unfolds; while k > 3 two symmetric half sweeps per iteration (the pairs inside "
+                               "the two halves of the points, the pairs between them), each priced with half the "
+                               "iteration's algorithmic bytes; (and whole-matrix row-owner launches where the symmetric "
+                               "sweep does not apply)"),
         "stage_kernel_with_check": priced(fused_ms, fused_launches, bytes_iter * fused_launches,
                                           "slab_stage_pipe_kernel<5,float,...,ERR=true>", "row-owner whole-matrix "
                                           "launch that also reduces the previous check's MAE"),

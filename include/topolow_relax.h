@@ -530,6 +530,14 @@ int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t
 /* Stage count the adaptive policy picks for spring constant k in ndim dimensions: the smallest power of two
  * with k / stages <= min(3, ndim) (a stage is a Jacobi step, stable for k / stages < 2 ndim). */
 int32_t topolow_slab_stages_for_k(double k, int32_t ndim);
+/* Two-stage iterations of sessions that take the symmetric sweep (fp32 / f64 slab schedule, ndim 2..6, >= 7168 points,
+ * whole matrix) run as two symmetric HALF sweeps: the pairs inside either half of the (randomly labelled) points -- labels
+ * [0, split) and [split, n), split = topolow_symm_half_split(n) -- and the pairs between the halves; every point meets
+ * half of its partners per stage, as in the row-owner form, and both ends of a pair move in the same stage, as in the
+ * reference.  topolow_symm_half_first: which of the two comes first in iteration `iter` (0: inside, 1: between).
+ * TOPOLOW_SYMMETRIC_TWO_STAGE=0 keeps the row-owner stages. */
+int32_t topolow_symm_half_split(int32_t n);
+int32_t topolow_symm_half_first(uint64_t seed, int32_t iter);
 /* Stage count of iteration `iter` (0-based) when slab_stages = 0: the policy above, and at least 16 stages
  * during the first 8 iterations, while the layout unfolds from its start. */
 int32_t topolow_slab_stages_at(int32_t iter, double k, int32_t ndim);

@@ -128,6 +128,46 @@ inline SymPlan relax_symm_plan(int npad, int n_waves, long long t0 = 0, long lon
   return P;
 }
 
+// The plan of an arbitrary set of tiles given per tile-row as ONE interval of column blocks: rows_j(R, j0, j1) sets the
+// interval [j0, j1) of tile-row R (j0 >= 2 R; empty when j0 >= j1).  Equal runs per wave as above; row_units covers all
+// tile-rows.  Used for the two halves of a two-stage iteration (topolow_relax.hip: sym_half_stage).
+template <typename RowsJ>
+inline SymPlan relax_symm_plan_rows(int npad, int n_waves, RowsJ rows_j) {
+  SymPlan P;
+  const int TR = npad / kSymRows, TC = npad / kSymCols;
+  long long total = 0;
+  for (int R = 0; R < TR; ++R) {
+    int j0 = 0, j1 = 0;
+    rows_j(R, j0, j1);
+    if (j1 > j0) total += j1 - j0;
+  }
+  P.wave_first.assign(n_waves + 1, 0);
+  P.row_units.assign(TR, int2{0, 0});
+  if (total == 0) return P;
+  long long done = 0;
+  int w = 0;
+  long long w_end = (total * (w + 1) + n_waves - 1) / n_waves;
+  for (int R = 0; R < TR; ++R) {
+    P.row_units[R].x = (int)P.units.size();
+    int j = 0, j_end = 0;
+    rows_j(R, j, j_end);
+    while (j < j_end) {
+      while (done >= w_end && w + 1 < n_waves) {
+        ++w;
+        P.wave_first[w] = (int)P.units.size();
+        w_end = (total * (w + 1) + n_waves - 1) / n_waves;
+      }
+      const int take = (int)std::min<long long>(j_end - j, std::max<long long>(w_end - done, 1));
+      P.units.push_back({R, j, j + take, (int)sym_tile_index(R, j, TC)});
+      j += take;
+      done += take;
+    }
+    P.row_units[R].y = (int)P.units.size() - P.row_units[R].x;
+  }
+  for (int q = w + 1; q <= n_waves; ++q) P.wave_first[q] = (int)P.units.size();
+  return P;
+}
+
 typedef float symf2 __attribute__((ext_vector_type(2)));
 #ifdef TOPOLOW_SYM_STAMPS
 __device__ unsigned long long* g_sym_stamps = nullptr;   // [4 * waves]: shader cycles of the wave's lifetime, its start and end on the 100-MHz counter, (XCC_ID, HW_ID)
@@ -479,7 +519,7 @@ template <int DIM>
 __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
     const float* __restrict__ rec, float* __restrict__ rec_next, float* __restrict__ pos_out, const float* __restrict__ gplus,
     const float* __restrict__ rowpart, const float* __restrict__ colpart, const int2* __restrict__ row_units, int n,
-    int npad, double k_next, double c_rep, int iter1, RunState* st) {
+    int npad, double k_next, double c_rep, int iter1, RunState* st, int split = 0, int mode = 0) {
   if (st != nullptr && st->stopped) return;
   constexpr int W = SymRec<DIM>::W;
   constexpr int kWavesA = kSymApplyParts / 2;
@@ -491,8 +531,13 @@ __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc[d] = 0.0f;
   // column sums of the tile-rows above (added), this thread's share: R' = part, part + 16, ... (independent loads: all
-  // of a thread's strips are in flight together)
-  for (int Rp = part; Rp < R; Rp += kSymApplyParts) {
+  // of a thread's strips are in flight together).  mode 1 / 2: a HALF stage of a two-stage iteration swept only the tiles
+  // whose rows and columns lie in the same / in different halves of the tile-rows (cut at `split`): only those tile-rows'
+  // sums are this sweep's, the other slots hold an older sweep's
+  int rp0 = 0, rp1 = R;
+  if (mode == 1) rp0 = R < split ? 0 : split;
+  else if (mode == 2) rp1 = R < split ? 0 : split;
+  for (int Rp = rp0 + part; Rp < rp1; Rp += kSymApplyParts) {
     const float* src = colpart + ((size_t)Rp * npad + i) * DIM;
 #pragma unroll
     for (int d = 0; d < DIM; ++d) acc[d] += src[d];

@@ -281,6 +281,17 @@ struct topolow_session {
     DevBuf<double> rec64[2], rowpart64, colpart64;   // f64 sessions (relax_symm64.h)
     DevBuf<float> tdelta;          // ... exact target - decoded word per cell of tenc: the fused check's MAE is exact
     bool delta_ready = false;
+    // two-stage iterations as two symmetric HALF sweeps (sym_half_stage): the tiles whose rows and columns lie in the
+    // same half of the tile-rows, then (or before) the tiles that pair the two halves
+    struct HalfPlan {
+      DevBuf<SymUnit> units;
+      DevBuf<SymRun> runs;
+      DevBuf<int2> row_units;
+      int n_units = 0;
+    } half[2];
+    int split = 0;                 // tile-rows [0, split) are the first half
+    bool half_ready = false;
+    bool two_stage = true;         // TOPOLOW_SYMMETRIC_TWO_STAGE=0: two-stage iterations stay on the row-owner kernel
     DevBuf<SymUnit> units;
     DevBuf<SymRun> wave_first;     // per wave of the grid: its run of units (relax_symm.h: SymPlan::runs)
     DevBuf<int2> row_units;
@@ -775,6 +786,30 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
     HIP_TRY(hipMemcpy(y.wave_first.p, runs.data(), runs.size() * sizeof(SymRun), hipMemcpyHostToDevice));
     if (!plan.row_units.empty())
       HIP_TRY(hipMemcpy(y.row_units.p, plan.row_units.data(), plan.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
+    y.half_ready = false;
+    int max_units = y.n_units;
+    if (t0 == 0 && (long long)y.tiles == (long long)TR * (TR + 1) && TR >= 4) {
+      y.split = TR / 2;
+      const int sp = y.split;
+      for (int which = 0; which < 2; ++which) {
+        const SymPlan hp = relax_symm_plan_rows(y.npad, y.grid * kSymWaves, [&](int R, int& j0, int& j1) {
+          if (which == 0) { j0 = 2 * R; j1 = R < sp ? 2 * sp : TC; }          // same half
+          else { j0 = 2 * sp; j1 = R < sp ? TC : 2 * sp; }                    // first-half rows x second-half columns
+        });
+        auto& h = y.half[which];
+        h.n_units = (int)hp.units.size();
+        max_units = std::max(max_units, h.n_units);
+        const std::vector<SymRun> hr = hp.runs();
+        h.units.alloc(std::max<size_t>(hp.units.size(), 1));
+        h.runs.alloc(hr.size());
+        h.row_units.alloc(hp.row_units.size());
+        if (!hp.units.empty())
+          HIP_TRY(hipMemcpy(h.units.p, hp.units.data(), hp.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h.runs.p, hr.data(), hr.size() * sizeof(SymRun), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h.row_units.p, hp.row_units.data(), hp.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
+      }
+      y.half_ready = true;
+    }
     y.src_tab.alloc(src.size());
     y.src_row0.alloc(row0.size());
     HIP_TRY(hipMemcpy(y.src_tab.p, src.data(), src.size() * sizeof(const uint32_t*), hipMemcpyHostToDevice));
@@ -787,7 +822,7 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
     const int seg_rows = y.seg_last >= y.seg_first ? y.seg_last - y.seg_first + 1 : 1;
     if (f64) {
       for (auto& r : y.rec64) r.alloc((size_t)y.npad * SymRec64<DIM>::W);
-      y.rowpart64.alloc((size_t)std::max(y.n_units, 1) * kSymRows * DIM);
+      y.rowpart64.alloc((size_t)std::max(max_units, 1) * kSymRows * DIM);
       y.colpart64.alloc((size_t)seg_rows * y.npad * DIM);
       HIP_TRY(hipMemsetAsync(y.colpart64.p, 0, (size_t)seg_rows * y.npad * DIM * sizeof(double), s->stream));
       // the fused check needs the edge list to BE the block's measured cells and to be on the device in f64
@@ -803,7 +838,7 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
     } else {
       constexpr int W = SymRec<DIM>::W;
       for (auto& r : y.rec) r.alloc((size_t)y.npad * W);
-      y.rowpart.alloc((size_t)std::max(y.n_units, 1) * kSymRows * DIM);
+      y.rowpart.alloc((size_t)std::max(max_units, 1) * kSymRows * DIM);
       y.colpart.alloc((size_t)seg_rows * y.npad * DIM);
       // (a segment's first and last tile-row are partial: the columns its tiles never reach must read as zero)
       HIP_TRY(hipMemsetAsync(y.colpart.p, 0, (size_t)seg_rows * y.npad * DIM * sizeof(float), s->stream));
@@ -911,6 +946,65 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
     y.rec_cur ^= 1;
     y.rec_iter = iter + 1;
     if (err) s->fused_parts = y.n_units;
+    s->stage_launches += 1;
+  }
+}
+
+// One STAGE of a two-stage iteration as a symmetric half sweep.  The row-owner form of such an iteration gives every
+// point its halves of the pairs with one half of the points, then with the other half; the symmetric form splits the
+// PAIRS instead: `which` = 0 sweeps the pairs inside either half of the (randomly labelled) points, 1 the pairs between
+// the halves -- every point still meets half of its partners per stage (its own half, then the other one, or the
+// other way round: the order is drawn per iteration), both ends of a pair move in the same stage as in the reference
+// (src/optimization.cpp:245-281), and every pair is evaluated once per iteration instead of twice.  k_records: the
+// spring constant of the records the apply kernel leaves (this iteration's after the first stage, the next one's after
+// the second).
+template <int DIM>
+void sym_half_stage(topolow_session* s, const void* pin, void* pout, int iter, double k, double k_records, int which,
+                    int rec_iter_after) {
+  if constexpr (!kSymDim<DIM>) {
+    throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
+  } else {
+    auto& y = s->sym;
+    auto& h = y.half[which];
+    ProfScope prof(s, &s->prof_stage);
+    const int TC = y.npad / kSymCols;
+    const bool f64 = s->precision == TOPOLOW_PRECISION_F64;
+    if (y.rec_iter != iter) {
+      for (int b = 0; b < 2; ++b) {
+        if (f64)
+          hipLaunchKernelGGL(symm64_records_kernel<DIM>, dim3((y.npad + 255) / 256), dim3(256), 0, s->stream, (const double*)pin,
+                             s->gplus.p, y.rec64[b].p, s->n, y.npad, k, s->c_rep);
+        else
+          hipLaunchKernelGGL(symm_records_kernel<DIM>, dim3((y.npad + 255) / 256), dim3(256), 0, s->stream, (const float*)pin,
+                             s->gplus.p, y.rec[b].p, s->n, y.npad, k, s->c_rep);
+      }
+      y.rec_cur = 0;
+    }
+    if (f64) {
+      const double* rec = y.rec64[y.rec_cur].p;
+      auto sweep = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec, h.units.p, h.runs.p,
+                           y.rowpart64.p, y.colpart64.p, y.npad, s->state.p, 0, (const float*)nullptr, s->part_sum.p,
+                           s->part_cnt.p, 0ull);
+      };
+      if (s->any_threshold) sweep(&symm64_sweep_kernel<DIM, true, false>); else sweep(&symm64_sweep_kernel<DIM, false, false>);
+      hipLaunchKernelGGL(symm64_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, s->stream, rec, y.rec64[y.rec_cur ^ 1].p,
+                         (double*)pout, s->gplus.p, y.rowpart64.p, y.colpart64.p, h.row_units.p, s->n, y.npad, k_records, s->c_rep,
+                         iter + 1, s->state.p, y.split, which + 1);
+    } else {
+      const float* rec = y.rec[y.rec_cur].p;
+      auto sweep = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(y.grid), dim3(64 * kSymWaves), 0, s->stream, y.tenc.p, rec, h.units.p, h.runs.p,
+                           y.rowpart.p, y.colpart.p, y.npad, s->state.p, s->part_sum.p, s->part_cnt.p, 0ull, 0);
+      };
+      if (s->any_threshold) sweep(&symm_sweep_kernel<DIM, true, false>); else sweep(&symm_sweep_kernel<DIM, false, false>);
+      hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, s->stream, rec, y.rec[y.rec_cur ^ 1].p,
+                         (float*)pout, s->gplus.p, y.rowpart.p, y.colpart.p, h.row_units.p, s->n, y.npad, k_records, s->c_rep,
+                         iter + 1, s->state.p, y.split, which + 1);
+    }
+    HIP_TRY(hipGetLastError());
+    y.rec_cur ^= 1;
+    y.rec_iter = rec_iter_after;
     s->stage_launches += 1;
   }
 }
@@ -1259,6 +1353,8 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     s->sym.allowed = !(symm != nullptr && symm[0] == '0');   // TOPOLOW_SYMMETRIC=0: row-owner sweeps only
     const char* symm_min = getenv("TOPOLOW_SYMMETRIC_MIN_N");   // tests lower the size gate to reach the sweep on small problems
     s->sym.min_n = symm_min != nullptr ? atoi(symm_min) : kSymMinPoints;
+    const char* symm2 = getenv("TOPOLOW_SYMMETRIC_TWO_STAGE");
+    s->sym.two_stage = !(symm2 != nullptr && symm2[0] == '0');
     s->enc.alloc((size_t)((s->rows() + kEncRowAlign - 1) / kEncRowAlign * kEncRowAlign) * s->ld);
     const size_t pos_bytes = (size_t)s->pos_rows() * s->dim * s->real_size();
     for (auto& b : s->pos) b.alloc(pos_bytes);
@@ -1600,11 +1696,21 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         const bool fuse_now = s->pcheck.active && g.n_stages == 1 &&
                               (s->precision == TOPOLOW_PRECISION_F64 ? (sym && s->sym.delta_ready) : (sym || s->rows() % 2 == 0));
         if (s->pcheck.active && !fuse_now) flush_pending_check(s);
+        const bool sym2 = g.n_stages == 2 && s->sym.two_stage && sym_eligible(s) && sym_available(s) && s->sym.half_ready;
         if (sym) {   // one sweep over the upper triangle moves both ends of every pair
           int out = 0;
           while (out == s->cur || out == s->held) ++out;
           TL_DISPATCH_DIM(s->dim, sym_iteration, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host, fuse_now);
           s->cur = out;
+        } else if (sym2) {   // two symmetric half sweeps: the pairs inside the halves and the pairs between them, in random order
+          const int first = (int)(rnd64(s->seed, 0x2a1f5ull, (uint64_t)iter) & 1u);
+          for (int t = 0; t < 2; ++t) {
+            int out = 0;
+            while (out == s->cur || out == s->held) ++out;
+            TL_DISPATCH_DIM(s->dim, sym_half_stage, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host,
+                            t == 0 ? s->k_host : s->k_host * (1.0 - s->cooling), first ^ t, t == 0 ? iter : iter + 1);
+            s->cur = out;
+          }
         } else
         for (int slot = 0; slot < g.n_stages; ++slot) {
           const SlabRanges rg = slab_ranges(g, s->seed, iter, slot);
@@ -1911,6 +2017,13 @@ int topolow_session_controller_step(topolow_session* s, const double* d_total2, 
     s->iters_enqueued = std::max(s->iters_enqueued, (int)iter1);
   });
 }
+
+int32_t topolow_symm_half_split(int32_t n) {
+  const int npad = (n + kSymRows - 1) & ~(kSymRows - 1);
+  const int split = (npad / kSymRows / 2) * kSymRows;
+  return split < n ? split : n;
+}
+int32_t topolow_symm_half_first(uint64_t seed, int32_t iter) { return (int32_t)(rnd64(seed, 0x2a1f5ull, (uint64_t)iter) & 1u); }
 
 int32_t topolow_symm_segment_rows(int32_t n, int32_t segment, int32_t n_segments, int32_t* row_first,
                                   int32_t* row_end) {
