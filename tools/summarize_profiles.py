@@ -29,6 +29,10 @@ for f in glob.glob(prefix + "_kt/*/*_kernel_trace.csv"):
         full = [x for x in v if x >= 52000]
         small = [x for x in v if x < 20000]
         half = [x for x in v if 20000 <= x < 52000]
+        if "symm_sweep_kernel" in k:     # whole-triangle sweeps (one-stage iterations) against half sweeps (two-stage ones)
+            full = [x for x in v if x >= 38000]
+            half = [x for x in v if 10000 <= x < 38000]
+            small = [x for x in v if x < 10000]
         mean = lambda xs: (sum(xs) / len(xs) / 1e3) if xs else None
         # the trace covers whole rotations of the job, so the mean over ALL launches of the plain instance is the mean over
         # the job's mix of sixteen-, two- and one-stage launches: what bench.py's by_kind.stage_kernel.avg_launch_us prices
@@ -38,6 +42,8 @@ for f in glob.glob(prefix + "_kt/*/*_kernel_trace.csv"):
         out[k] = dict(launches=len(v), mean_us=sum(v) / len(v) / 1e3, sixteen_stage_launches=len(small),
                       sixteen_stage_mean_us=mean(small), two_stage_launches=len(half), two_stage_mean_us=mean(half),
                       job_mix_mean_us=job_mix,
+                      classes=("whole-triangle sweeps >= 38 us / half sweeps 10-38 us / early exits < 10 us" if "symm_sweep_kernel" in k
+                               else "by duration: one-stage >= 52 us, two-stage 20-52 us, sixteen-stage < 20 us"),
                       one_stage_launches=len(full), one_stage_mean_us=(sum(full) / len(full) / 1e3) if full else None,
                       one_stage_min_us=min(full) / 1e3 if full else None, one_stage_max_us=max(full) / 1e3 if full else None)
     json.dump(out, open(f"profiles/{tag}_stage_kernel_trace.json", "w"), indent=1, sort_keys=True)
@@ -56,6 +62,10 @@ for sub in ("fetch", "write", "sq"):
             # config 3 (two-stage launches take ~40 us, sixteen-stage ones ~9 us)
             if "slab_stage_" in name and dur >= 52000:
                 names.append(name + " [one-stage launches]")
+            # the symmetric sweep is also launched on half the tiles (the two stages of a two-stage iteration, ~25 us
+            # at config 3): the whole-triangle sweeps of one-stage iterations are those of >= 38 us
+            if "symm_sweep_kernel" in name:
+                names.append(name + (" [whole-triangle sweeps]" if dur >= 38000 else " [half sweeps]"))
             for nm in names:
                 agg[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 agg[nm]["_dur_ns"].append(dur)
@@ -74,7 +84,7 @@ for k, v in summary.items():
     if "hbm_read_bytes_per_launch" in v and "hbm_write_bytes_per_launch" in v:
         v["hbm_traffic_bytes_per_launch"] = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
 # one symmetric one-stage iteration = its sweep (plain instance) + its apply: the entry bench.py's roofline.traffic reads
-sw = [k for k in summary if "symm_sweep_kernel<5, false, false>" in k]
+sw = [k for k in summary if "symm_sweep_kernel<5, false, false>" in k and "[whole-triangle sweeps]" in k]
 ap = [k for k in summary if "symm_apply_kernel<5>" in k]
 if sw and ap and "hbm_traffic_bytes_per_launch" in summary[sw[0]] and "hbm_traffic_bytes_per_launch" in summary[ap[0]]:
     a, b = summary[sw[0]], summary[ap[0]]
