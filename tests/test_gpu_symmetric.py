@@ -85,7 +85,8 @@ def test_symmetric_sweep_reports_a_diverging_run():
 
 def test_single_block_engine_run_takes_the_symmetric_sweep_too():
     """topolow_sessions_run_sharded with ONE block (the whole matrix) and the session's own loop run the same
-    kernels in the same order: bit-identical positions, same checks."""
+    kernels in the same order -- row-owner stages while the layout unfolds, two symmetric half sweeps per two-stage
+    iteration, the symmetric sweep afterwards: bit-identical positions, same checks."""
     n, dim = 7205, 3
     call, _ = pp.random_problem(n, dim, 0.7, seed=21, n_iter=10, k0=1.5)
 
@@ -96,13 +97,13 @@ def test_single_block_engine_run_takes_the_symmetric_sweep_too():
         return s
     s = make()
     s.set_positions(call.initial_positions)
-    s.begin(40, 2.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 5, 0)
+    s.begin(60, 4.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 5, 0)       # 8 iterations of 16 stages, 21 of two (half sweeps), 31 of one
     s.run()
     s.sync()
     a, ta = s.finish(), s.check_trace()
     s.close()
     s = make()
-    b = _native.run_sharded([s], call.initial_positions, 40, 2.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 5, 0)
+    b = _native.run_sharded([s], call.initial_positions, 60, 4.0, 0.01, 0.01, 1e-4, 10 ** 9, 3, 5, 0)
     tb = s.check_trace()
     s.close()
     assert np.array_equal(a.positions, b.positions)

@@ -202,6 +202,16 @@ inline void sharded_worker(ShardedRun& R, int r) {
       }
       if (!exchange()) return;
       cur = nxt;
+    } else if (R.P == 1 && geo.n_stages == 2 && lead->sym.two_stage && sym_eligible(lead) && sym_available(lead) &&
+               lead->sym.half_ready) {
+      // ONE block = the whole matrix: a two-stage iteration as two symmetric half sweeps, as in the session's own loop
+      const int first = (int)(rnd64(lead->seed, 0x2a1f5ull, (uint64_t)iter) & 1u);
+      for (int t = 0; t < 2; ++t) {
+        TL_DISPATCH_DIM(lead->dim, sym_half_stage, lead, lead->pos[cur].p, lead->pos[(cur + 1) % 3].p, iter, k,
+                        t == 0 ? k : k * (1.0 - R.cooling), first ^ t, t == 0 ? iter : iter + 1);
+        if (!exchange()) return;
+        cur = (cur + 1) % 3;
+      }
     } else
     for (int slot = 0; slot < geo.n_stages; ++slot) {
       const SlabRanges rg = slab_ranges(geo, lead->seed, iter, slot);
