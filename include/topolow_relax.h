@@ -64,7 +64,12 @@ extern "C" {
  *         a row-sharded run shards it over its sessions (same band against one block); f64 sessions take an f64 form
  *         of it (csrc/relax_symm64.h; equal to the f64 CPU model to 1e-12 per iteration; its fused check is exact --
  *         the sweep also reads exact-minus-rounded target differences -- and equals the reference's edge MAE to 1e-11);
- *         TOPOLOW_SYMMETRIC=0 / TOPOLOW_SHARD_SYMMETRIC=0 switch it off.
+ *         TOPOLOW_SYMMETRIC=0 / TOPOLOW_SHARD_SYMMETRIC=0 switch it off.  Where the sweep applies, TWO-stage iterations
+ *         (3 < k <= 6) run as two symmetric half sweeps -- the pairs inside the two halves of the randomly labelled
+ *         points, the pairs between them, in random order -- instead of "all points against half the columns, twice":
+ *         every point still meets half of its partners per stage, both ends of a pair move together as in the reference;
+ *         equal to a CPU model of that schedule (f64: 1e-12 per stage), final-MAE statistics unchanged on the pinned
+ *         problems (64 seeds each: profiles/r03_two_stage_study.txt); TOPOLOW_SYMMETRIC_TWO_STAGE=0 keeps the row-owner form.
  * The deterministic pieces -- controller, cooling, error rule, guards, messages -- are exact. */
 
 /* Schedules (topolow_options.schedule). */
