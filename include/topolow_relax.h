@@ -64,12 +64,14 @@ extern "C" {
  *         a row-sharded run shards it over its sessions (same band against one block); f64 sessions take an f64 form
  *         of it (csrc/relax_symm64.h; equal to the f64 CPU model to 1e-12 per iteration; its fused check is exact --
  *         the sweep also reads exact-minus-rounded target differences -- and equals the reference's edge MAE to 1e-11);
- *         TOPOLOW_SYMMETRIC=0 / TOPOLOW_SHARD_SYMMETRIC=0 switch it off.  Where the sweep applies, TWO-stage iterations
- *         (3 < k <= 6) run as two symmetric half sweeps -- the pairs inside the two halves of the randomly labelled
- *         points, the pairs between them, in random order -- instead of "all points against half the columns, twice":
- *         every point still meets half of its partners per stage, both ends of a pair move together as in the reference;
- *         equal to a CPU model of that schedule (f64: 1e-12 per stage), final-MAE statistics unchanged on the pinned
- *         problems (64 seeds each: profiles/r03_two_stage_study.txt); TOPOLOW_SYMMETRIC_TWO_STAGE=0 keeps the row-owner form.
+ *         TOPOLOW_SYMMETRIC=0 / TOPOLOW_SHARD_SYMMETRIC=0 switch it off.  Where the sweep applies, 2-, 4- and 8-stage
+ *         iterations whose stages leave a resident wave >= 5 tiles (config 3: the two-stage ones, 3 < k <= 6) run as S
+ *         symmetric sweeps that split the PAIRS -- stage st: the pairs between slabs a and b of the randomly labelled
+ *         points with (a + b) mod S == st, stages in random order -- instead of "all points against one slab of the
+ *         columns, S times": every point still meets one slab of partners per stage, both ends of a pair move together as
+ *         in the reference; equal to a CPU model of that schedule (f64: 1e-12 per stage), final-MAE statistics unchanged
+ *         on the pinned problems and seed for seed (profiles/r03_two_stage_study.txt); TOPOLOW_SYMMETRIC_TWO_STAGE=0
+ *         keeps the row-owner form.
  * The deterministic pieces -- controller, cooling, error rule, guards, messages -- are exact. */
 
 /* Schedules (topolow_options.schedule). */
@@ -535,14 +537,15 @@ int32_t topolow_slab_plan(int32_t n, int32_t slab_stages, uint64_t seed, int32_t
 /* Stage count the adaptive policy picks for spring constant k in ndim dimensions: the smallest power of two
  * with k / stages <= min(3, ndim) (a stage is a Jacobi step, stable for k / stages < 2 ndim). */
 int32_t topolow_slab_stages_for_k(double k, int32_t ndim);
-/* Two-stage iterations of sessions that take the symmetric sweep (fp32 / f64 slab schedule, ndim 2..6, >= 7168 points,
- * whole matrix) run as two symmetric HALF sweeps: the pairs inside either half of the (randomly labelled) points -- labels
- * [0, split) and [split, n), split = topolow_symm_half_split(n) -- and the pairs between the halves; every point meets
- * half of its partners per stage, as in the row-owner form, and both ends of a pair move in the same stage, as in the
- * reference.  topolow_symm_half_first: which of the two comes first in iteration `iter` (0: inside, 1: between).
+/* 2-, 4- and 8-stage iterations of sessions that take the symmetric sweep (fp32 / f64 slab schedule, ndim 2..6, >= 7168
+ * points, whole matrix) run as symmetric sweeps that split the PAIRS: the (randomly labelled) points are cut into S slabs
+ * of labels [first_label[q], first_label[q + 1]) and stage st sweeps the pairs between slabs a and b with
+ * (a + b) mod S == st, so every point meets one slab of partners per stage, as in the row-owner form, and both ends of a
+ * pair move in the same stage, as in the reference.  topolow_symm_stage_bounds: the S + 1 slab boundaries (0 when the
+ * problem is too small or S is not 2, 4, 8); topolow_symm_stage_order: the order of the stages in iteration `iter`.
  * TOPOLOW_SYMMETRIC_TWO_STAGE=0 keeps the row-owner stages. */
-int32_t topolow_symm_half_split(int32_t n);
-int32_t topolow_symm_half_first(uint64_t seed, int32_t iter);
+int32_t topolow_symm_stage_bounds(int32_t n, int32_t stages, int32_t* first_label);
+int32_t topolow_symm_stage_order(uint64_t seed, int32_t iter, int32_t stages, int32_t* order);
 /* Stage count of iteration `iter` (0-based) when slab_stages = 0: the policy above, and at least 16 stages
  * during the first 8 iterations, while the layout unfolds from its start. */
 int32_t topolow_slab_stages_at(int32_t iter, double k, int32_t ndim);

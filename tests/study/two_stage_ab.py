@@ -1,4 +1,4 @@
-"""GPU study: two-stage iterations as symmetric half sweeps against the row-owner stages, seed for seed, on problems
+"""GPU study: multi-stage iterations as symmetric sweeps (TOPOLOW_SYMMETRIC_TWO_STAGE) against the row-owner stages, seed for seed, on problems
 without an oracle distribution -- config 3b at full size (10 % of the measured pairs censored), a stiffer spring
 (k0 = 6: the longest two-stage phase the policy allows) and f64.  usage: python tests/study/two_stage_ab.py [seeds]"""
 import os
@@ -14,7 +14,11 @@ from topolow_amd import _native  # noqa: E402
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cases = [("config 3b (10 % censored), fp32", pp.cfg3_generator(10000, censored=0.1)[0], "f32"),
          ("config 3, k0 = 6, fp32", pp.cfg3_generator(10000, k0=6.0)[0], "f32"),
-         ("config 3, f64", pp.cfg3_generator(10000)[0], "f64")]
+         ("config 3, f64", pp.cfg3_generator(10000)[0], "f64"),
+         ("config 3, k0 = 12 (4-, 2-, 1-stage phases), fp32", pp.cfg3_generator(10000, k0=12.0)[0], "f32"),
+         ("config 3, k0 = 20 (8-, 4-, 2-, 1-stage phases), fp32", pp.cfg3_generator(10000, k0=20.0)[0], "f32")]
+if len(sys.argv) > 2:
+    cases = [c for c in cases if sys.argv[2] in c[0]]
 for name, call, prec in cases:
     out = {}
     for v in ("1", "0"):

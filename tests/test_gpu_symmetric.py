@@ -408,24 +408,22 @@ def test_symmetric_sweep_f64_fuzz_through_the_production_entry():
 
 
 # ----------------------------------------------------------------------------------------
-# two-stage iterations as two symmetric half sweeps (the pairs inside the halves of the points, the pairs between them)
+# 2-, 4- and 8-stage iterations as symmetric sweeps that split the PAIRS (stage st: slab a meets slab (st - a) mod S)
 # ----------------------------------------------------------------------------------------
-def _two_stage_model(call_r, iters, k0, cooling, c_rep, seed):
-    """The CPU model of that iteration in f64: per stage every point moves by the sum of its own halves of its pairs with
-    ONE half of the points -- its own half in the `inside` stage, the other one in the `between` stage -- from the
-    positions the previous stage left (slab_model.stage gives every row its move from a range of columns)."""
+def _multi_stage_model(call_r, iters, k0, cooling, c_rep, seed, stages):
+    """The CPU model of that schedule in f64: in stage st every point of slab c moves by the sum of its own halves of its
+    pairs with the points of slab (st - c) mod S, from the positions the previous stage left (slab_model.stage gives
+    every row its move from a range of columns)."""
     n = call_r.initial_positions.shape[0]
-    split = _native.symm_half_split(n)
+    bounds = _native.symm_stage_bounds(n, stages)
     out, pos, k = [], call_r.initial_positions, k0
     args = (call_r.dissimilarity_matrix, call_r.threshold_matrix, call_r.degrees)
     for it in range(iters):
-        first = _native.symm_half_first(seed, it)
-        for which in (first, first ^ 1):
-            lo = slab_model.stage(pos, *args, [[0, split]], k, c_rep, "f64")     # every row against the first half's columns
-            hi = slab_model.stage(pos, *args, [[split, n]], k, c_rep, "f64")
+        for st in _native.symm_stage_order(seed, it, stages):
+            against = [slab_model.stage(pos, *args, [[bounds[q], bounds[q + 1]]], k, c_rep, "f64") for q in range(stages)]
             new = np.empty_like(pos)
-            new[:split] = (lo if which == 0 else hi)[:split]
-            new[split:] = (hi if which == 0 else lo)[split:]
+            for c in range(stages):
+                new[bounds[c]:bounds[c + 1]] = against[(st - c) % stages][bounds[c]:bounds[c + 1]]
             pos = new
         out.append(pos)
         k *= 1.0 - cooling
@@ -433,39 +431,41 @@ def _two_stage_model(call_r, iters, k0, cooling, c_rep, seed):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
-@pytest.mark.parametrize("n,dim,thr", [(300, 2, 0.0), (1000, 5, 0.15), (2973, 3, 0.0), (2973, 6, 0.15)])
-def test_two_stage_iterations_as_symmetric_half_sweeps_against_the_model(n, dim, thr, precision):
-    """Five two-stage iterations (slab_stages = 2) on the half sweeps against the CPU model of exactly that schedule:
+@pytest.mark.parametrize("n,dim,thr,stages", [(300, 2, 0.0, 2), (1000, 5, 0.15, 2), (2973, 3, 0.0, 2), (2973, 6, 0.15, 2),
+                                              (1000, 5, 0.15, 4), (2973, 3, 0.0, 8), (2050, 4, 0.15, 8)])
+def test_multi_stage_iterations_as_symmetric_sweeps_against_the_model(n, dim, thr, stages, precision):
+    """Four S-stage iterations (slab_stages = S) as S symmetric sweeps against the CPU model of exactly that schedule:
     f64 to 1e-12 of the displacement scale per stage, fp32 in the bands of the one-stage test; the separate checks
     against the oracle's edge error of the model's positions; and TOPOLOW_SYMMETRIC_TWO_STAGE=0 gives the row-owner
-    stages back (a different, equally valid two-stage schedule: not compared)."""
-    k0, cooling, c_rep, seed = 4.0, 0.01, 0.01, 5
-    call, _ = pp.random_problem(n, dim, 0.7 if n > 500 else 0.3, seed=300 + n % 50 + dim, n_iter=5, k0=k0)
+    stages back (a different, equally valid S-stage schedule: not compared)."""
+    k0, cooling, c_rep, seed, iters = 2.0 * stages, 0.01, 0.01, 5, 4
+    call, _ = pp.random_problem(n, dim, 0.7 if n > 500 else 0.3, seed=300 + n % 50 + dim, n_iter=iters, k0=k0)
     call = _with_thresholds(call, thr)
     call_r = dataclasses.replace(call, dissimilarity_matrix=_decode_rounded(call))
-    want = _two_stage_model(call_r, 5, k0, cooling, c_rep, seed)
+    want = _multi_stage_model(call_r, iters, k0, cooling, c_rep, seed, stages)
     scale = np.abs(want[-1] - call.initial_positions).max()
 
-    def run(two_stage):
-        with _Env(TOPOLOW_SYMMETRIC="1", TOPOLOW_SYMMETRIC_MIN_N="0", TOPOLOW_SYMMETRIC_TWO_STAGE=two_stage):
+    def run(symmetric_stages):
+        with _Env(TOPOLOW_SYMMETRIC="1", TOPOLOW_SYMMETRIC_MIN_N="0", TOPOLOW_SYMMETRIC_TWO_STAGE=symmetric_stages,
+                  TOPOLOW_SYMMETRIC_STAGE_MIN_TILES="0"):      # (production: a stage must give a resident wave ~3 tiles)
             s = _native.Session(n, dim, precision=precision)
         s.load_dense(call.dissimilarity_matrix, call.threshold_matrix, call.degrees)
         s.set_edges(call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
         s.set_positions(call.initial_positions)
-        s.begin(5, k0, cooling, c_rep, 1e-12, 10 ** 9, 2, seed, 2)
+        s.begin(iters, k0, cooling, c_rep, 1e-12, 10 ** 9, 2, seed, stages)
         s.run()
         s.sync()
         out = s.get_positions(), s.check_trace(), s.stage_launches
         s.close()
         return out
     got, trace, launches = run("1")
-    assert launches == 10
+    assert launches == iters * stages
     err = np.abs(got - want[-1])
     if precision == "f64":
-        assert err.max() <= 1e-12 * scale * 10, err.max() / scale
+        assert err.max() <= 1e-12 * scale * iters * stages, err.max() / scale
     else:
         assert err.mean() <= 5e-5 * scale and err.max() <= 5e-3 * scale, (err.mean() / scale, err.max() / scale)
-    assert [int(t) for t in trace[:, 0]] == [2, 4, 5]
+    assert [int(t) for t in trace[:, 0]] == [2, 4]
     for row in trace:
         sm, c = orc.edge_error(want[int(row[0]) - 1], call.edge_i, call.edge_j, call.edge_dist, call.edge_thresh)
         assert row[1] == pytest.approx(sm / c, rel=1e-11 if precision == "f64" else 2e-5)

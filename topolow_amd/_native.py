@@ -210,10 +210,10 @@ def load() -> C.CDLL:
     lib.topolow_session_load_coo.restype = C.c_int
     lib.topolow_session_load_coo.argtypes = [vp, ip, ip, dp, ip, C.c_int64, ip, C.c_char_p,
                                              C.c_size_t]
-    lib.topolow_symm_half_split.restype = C.c_int32
-    lib.topolow_symm_half_split.argtypes = [C.c_int32]
-    lib.topolow_symm_half_first.restype = C.c_int32
-    lib.topolow_symm_half_first.argtypes = [C.c_uint64, C.c_int32]
+    lib.topolow_symm_stage_bounds.restype = C.c_int32
+    lib.topolow_symm_stage_bounds.argtypes = [C.c_int32, C.c_int32, ip]
+    lib.topolow_symm_stage_order.restype = C.c_int32
+    lib.topolow_symm_stage_order.argtypes = [C.c_uint64, C.c_int32, C.c_int32, ip]
     lib.topolow_symm_segment_rows.restype = C.c_int32
     lib.topolow_symm_segment_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, ip, ip]
     lib.topolow_session_has_thresholds.restype = C.c_int32
@@ -553,14 +553,17 @@ def cv_sweep(cells: CellList, named: bool, preserve_order: bool, ndims, k0s, coo
     return hsum, hcnt, its, conv, ec, float(secs.value)
 
 
-def symm_half_split(n: int) -> int:
-    """First label of the second half of a two-stage symmetric iteration (topolow_symm_half_split)."""
-    return int(load().topolow_symm_half_split(int(n)))
+def symm_stage_bounds(n: int, stages: int):
+    """Slab boundaries (labels) of the symmetric form of an S-stage iteration, or None (topolow_symm_stage_bounds)."""
+    out = np.zeros(stages + 1, dtype=np.int32)
+    return out.tolist() if load().topolow_symm_stage_bounds(int(n), int(stages), _ip(out)) else None
 
 
-def symm_half_first(seed: int, it: int) -> int:
-    """0: the pairs inside the halves come first in iteration `it`, 1: the pairs between them."""
-    return int(load().topolow_symm_half_first(C.c_uint64(seed), int(it)))
+def symm_stage_order(seed: int, it: int, stages: int):
+    """Order of the stages of iteration `it` (topolow_symm_stage_order)."""
+    out = np.zeros(stages, dtype=np.int32)
+    assert load().topolow_symm_stage_order(C.c_uint64(seed), int(it), int(stages), _ip(out))
+    return out.tolist()
 
 
 def symm_segment_rows(n: int, segment: int, n_segments: int):

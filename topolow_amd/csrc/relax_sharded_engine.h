@@ -202,13 +202,17 @@ inline void sharded_worker(ShardedRun& R, int r) {
       }
       if (!exchange()) return;
       cur = nxt;
-    } else if (R.P == 1 && geo.n_stages == 2 && lead->sym.two_stage && sym_eligible(lead) && sym_available(lead) &&
-               lead->sym.half_ready) {
-      // ONE block = the whole matrix: a two-stage iteration as two symmetric half sweeps, as in the session's own loop
-      const int first = (int)(rnd64(lead->seed, 0x2a1f5ull, (uint64_t)iter) & 1u);
-      for (int t = 0; t < 2; ++t) {
-        TL_DISPATCH_DIM(lead->dim, sym_half_stage, lead, lead->pos[cur].p, lead->pos[(cur + 1) % 3].p, iter, k,
-                        t == 0 ? k : k * (1.0 - R.cooling), first ^ t, t == 0 ? iter : iter + 1);
+    } else if (R.P == 1 && lead->sym.two_stage && sym_rr_stages_ok(geo.n_stages) && sym_eligible(lead) && sym_available(lead) &&
+               sym_rr_available(lead, geo.n_stages)) {
+      // ONE block = the whole matrix: a 2-, 4- or 8-stage iteration as symmetric sweeps over the tiles of one stage each,
+      // as in the session's own loop
+      const int S = geo.n_stages;
+      int order[8];
+      sym_rr_order(lead->seed, iter, S, order);
+      for (int t = 0; t < S; ++t) {
+        const bool last = t == S - 1;
+        TL_DISPATCH_DIM(lead->dim, sym_rr_stage, lead, lead->pos[cur].p, lead->pos[(cur + 1) % 3].p, iter, k,
+                        last ? k * (1.0 - R.cooling) : k, S, order[t], last ? iter + 1 : iter);
         if (!exchange()) return;
         cur = (cur + 1) % 3;
       }

@@ -128,6 +128,40 @@ inline SymPlan relax_symm_plan(int npad, int n_waves, long long t0 = 0, long lon
   return P;
 }
 
+// ---- multi-stage iterations on the symmetric sweep: S stages that split the PAIRS (S = 2, 4, 8) -----------------------
+// The tile-rows are cut into S slabs (tile-rows [q TR / S, (q + 1) TR / S)); stage st sweeps the pairs between slabs a and
+// b with (a + b) mod S == st -- for every slab a exactly one partner slab b = (st - a) mod S, itself included -- so over
+// the S stages every point meets each slab once, both ends of a pair move in the same stage, and every pair is evaluated
+// once per iteration.  In the upper triangle the pairs (a, b) live in the tile-rows of min(a, b).
+TL_HD inline int sym_rr_bound(int TR, int S, int q) { return (int)((long long)q * TR / S); }
+TL_HD inline int sym_rr_slab(int TR, int S, int R) {
+  int q = 0;
+  while (q + 1 < S && R >= sym_rr_bound(TR, S, q + 1)) ++q;
+  return q;
+}
+// The column blocks [j0, j1) of tile-row R that stage st sweeps (empty: j0 >= j1).
+TL_HD inline void sym_rr_row(int TR, int S, int st, int R, int& j0, int& j1) {
+  const int a = sym_rr_slab(TR, S, R), b = ((st - a) % S + S) % S;
+  if (b < a) { j0 = j1 = 0; return; }
+  j0 = b == a ? 2 * R : 2 * sym_rr_bound(TR, S, b);
+  j1 = 2 * sym_rr_bound(TR, S, b + 1);
+}
+// The tile-rows [rp0, rp1) whose column sums of stage st belong to a point of tile-row R (symm_apply_kernel).
+TL_HD inline void sym_rr_above(int TR, int S, int st, int R, int& rp0, int& rp1) {
+  const int c = sym_rr_slab(TR, S, R), a = ((st - c) % S + S) % S;
+  if (a > c) { rp0 = rp1 = 0; return; }
+  rp0 = sym_rr_bound(TR, S, a);
+  rp1 = a == c ? R : sym_rr_bound(TR, S, a + 1);
+}
+// The order of the stages in iteration `iter` (random per iteration, like the slabs of the row-owner form).
+TL_HD inline void sym_rr_order(uint64_t seed, int iter, int S, int* perm) {
+  for (int q = 0; q < S; ++q) perm[q] = q;
+  for (int q = S - 1; q > 0; --q) {
+    const uint32_t r = rnd_below(rnd64(seed, 0x2a1f5ull, ((uint64_t)iter << 8) | (uint64_t)q), (uint32_t)(q + 1));
+    const int tmp = perm[q]; perm[q] = perm[r]; perm[r] = tmp;
+  }
+}
+
 // The plan of an arbitrary set of tiles given per tile-row as ONE interval of column blocks: rows_j(R, j0, j1) sets the
 // interval [j0, j1) of tile-row R (j0 >= 2 R; empty when j0 >= j1).  Equal runs per wave as above; row_units covers all
 // tile-rows.  Used for the two halves of a two-stage iteration (topolow_relax.hip: sym_half_stage).
@@ -519,7 +553,7 @@ template <int DIM>
 __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
     const float* __restrict__ rec, float* __restrict__ rec_next, float* __restrict__ pos_out, const float* __restrict__ gplus,
     const float* __restrict__ rowpart, const float* __restrict__ colpart, const int2* __restrict__ row_units, int n,
-    int npad, double k_next, double c_rep, int iter1, RunState* st, int split = 0, int mode = 0) {
+    int npad, double k_next, double c_rep, int iter1, RunState* st, int rr_stages = 0, int rr_stage = 0) {
   if (st != nullptr && st->stopped) return;
   constexpr int W = SymRec<DIM>::W;
   constexpr int kWavesA = kSymApplyParts / 2;
@@ -531,12 +565,11 @@ __global__ __launch_bounds__(32 * kSymApplyParts) void symm_apply_kernel(
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc[d] = 0.0f;
   // column sums of the tile-rows above (added), this thread's share: R' = part, part + 16, ... (independent loads: all
-  // of a thread's strips are in flight together).  mode 1 / 2: a HALF stage of a two-stage iteration swept only the tiles
-  // whose rows and columns lie in the same / in different halves of the tile-rows (cut at `split`): only those tile-rows'
-  // sums are this sweep's, the other slots hold an older sweep's
+  // of a thread's strips are in flight together).  rr_stages > 0: the sweep was ONE STAGE of a multi-stage iteration
+  // (sym_rr_*: the tiles that pair this point's slab with its partner slab of the stage): only those tile-rows' sums are
+  // this sweep's, the other slots hold an older sweep's
   int rp0 = 0, rp1 = R;
-  if (mode == 1) rp0 = R < split ? 0 : split;
-  else if (mode == 2) rp1 = R < split ? 0 : split;
+  if (rr_stages > 0) sym_rr_above(npad / kSymRows, rr_stages, rr_stage, R, rp0, rp1);
   for (int Rp = rp0 + part; Rp < rp1; Rp += kSymApplyParts) {
     const float* src = colpart + ((size_t)Rp * npad + i) * DIM;
 #pragma unroll

@@ -305,7 +305,7 @@ template <int DIM>
 __global__ __launch_bounds__(32 * kSymApplyParts) void symm64_apply_kernel(
     const double* __restrict__ rec, double* __restrict__ rec_next, double* __restrict__ pos_out, const float* __restrict__ gplus,
     const double* __restrict__ rowpart, const double* __restrict__ colpart, const int2* __restrict__ row_units, int n,
-    int npad, double k_next, double c_rep, int iter1, RunState* st, int split = 0, int mode = 0) {
+    int npad, double k_next, double c_rep, int iter1, RunState* st, int rr_stages = 0, int rr_stage = 0) {
   if (st != nullptr && st->stopped) return;
   constexpr int W = SymRec64<DIM>::W;
   constexpr int kWavesA = kSymApplyParts / 2;
@@ -316,9 +316,8 @@ __global__ __launch_bounds__(32 * kSymApplyParts) void symm64_apply_kernel(
   double acc[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; ++d) acc[d] = 0.0;
-  int rp0 = 0, rp1 = R;           // (mode, split: as symm_apply_kernel)
-  if (mode == 1) rp0 = R < split ? 0 : split;
-  else if (mode == 2) rp1 = R < split ? 0 : split;
+  int rp0 = 0, rp1 = R;           // (rr_stages, rr_stage: as symm_apply_kernel)
+  if (rr_stages > 0) sym_rr_above(npad / kSymRows, rr_stages, rr_stage, R, rp0, rp1);
   for (int Rp = rp0 + part; Rp < rp1; Rp += kSymApplyParts) {
     const double* src = colpart + ((size_t)Rp * npad + i) * DIM;
 #pragma unroll

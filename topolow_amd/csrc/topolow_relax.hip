@@ -281,17 +281,18 @@ struct topolow_session {
     DevBuf<double> rec64[2], rowpart64, colpart64;   // f64 sessions (relax_symm64.h)
     DevBuf<float> tdelta;          // ... exact target - decoded word per cell of tenc: the fused check's MAE is exact
     bool delta_ready = false;
-    // two-stage iterations as two symmetric HALF sweeps (sym_half_stage): the tiles whose rows and columns lie in the
-    // same half of the tile-rows, then (or before) the tiles that pair the two halves
-    struct HalfPlan {
+    // multi-stage iterations (2, 4, 8 stages) as symmetric sweeps over the tiles of one stage each (relax_symm.h:
+    // sym_rr_*; sym_rr_stage below): rr[log2 S] holds the S plans, built when an iteration first needs them
+    struct StagePlan {
       DevBuf<SymUnit> units;
       DevBuf<SymRun> runs;
       DevBuf<int2> row_units;
       int n_units = 0;
-    } half[2];
-    int split = 0;                 // tile-rows [0, split) are the first half
-    bool half_ready = false;
-    bool two_stage = true;         // TOPOLOW_SYMMETRIC_TWO_STAGE=0: two-stage iterations stay on the row-owner kernel
+    };
+    std::vector<StagePlan> rr[4];
+    bool whole = false;            // the buffers describe the whole triangle (not a segment): stage plans may be cut from it
+    bool two_stage = true;         // TOPOLOW_SYMMETRIC_TWO_STAGE=0: multi-stage iterations stay on the row-owner kernel
+    int rr_min_tiles = 5;          // tiles per resident wave a stage must have (TOPOLOW_SYMMETRIC_STAGE_MIN_TILES; tests: 0)
     DevBuf<SymUnit> units;
     DevBuf<SymRun> wave_first;     // per wave of the grid: its run of units (relax_symm.h: SymPlan::runs)
     DevBuf<int2> row_units;
@@ -786,30 +787,10 @@ void sym_build(topolow_session* s, const std::vector<const uint32_t*>& src, cons
     HIP_TRY(hipMemcpy(y.wave_first.p, runs.data(), runs.size() * sizeof(SymRun), hipMemcpyHostToDevice));
     if (!plan.row_units.empty())
       HIP_TRY(hipMemcpy(y.row_units.p, plan.row_units.data(), plan.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
-    y.half_ready = false;
-    int max_units = y.n_units;
-    if (t0 == 0 && (long long)y.tiles == (long long)TR * (TR + 1) && TR >= 4) {
-      y.split = TR / 2;
-      const int sp = y.split;
-      for (int which = 0; which < 2; ++which) {
-        const SymPlan hp = relax_symm_plan_rows(y.npad, y.grid * kSymWaves, [&](int R, int& j0, int& j1) {
-          if (which == 0) { j0 = 2 * R; j1 = R < sp ? 2 * sp : TC; }          // same half
-          else { j0 = 2 * sp; j1 = R < sp ? TC : 2 * sp; }                    // first-half rows x second-half columns
-        });
-        auto& h = y.half[which];
-        h.n_units = (int)hp.units.size();
-        max_units = std::max(max_units, h.n_units);
-        const std::vector<SymRun> hr = hp.runs();
-        h.units.alloc(std::max<size_t>(hp.units.size(), 1));
-        h.runs.alloc(hr.size());
-        h.row_units.alloc(hp.row_units.size());
-        if (!hp.units.empty())
-          HIP_TRY(hipMemcpy(h.units.p, hp.units.data(), hp.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h.runs.p, hr.data(), hr.size() * sizeof(SymRun), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h.row_units.p, hp.row_units.data(), hp.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
-      }
-      y.half_ready = true;
-    }
+    y.whole = t0 == 0 && (long long)y.tiles == (long long)TR * (TR + 1);
+    for (auto& v : y.rr) v.clear();
+    // a stage plan has at most one unit per wave and one more per tile-row and interval end
+    const int max_units = std::max(y.n_units, y.grid * kSymWaves + 2 * TR + 8);
     y.src_tab.alloc(src.size());
     y.src_row0.alloc(row0.size());
     HIP_TRY(hipMemcpy(y.src_tab.p, src.data(), src.size() * sizeof(const uint32_t*), hipMemcpyHostToDevice));
@@ -950,22 +931,55 @@ void sym_iteration(topolow_session* s, const void* pin, void* pout, int iter, do
   }
 }
 
-// One STAGE of a two-stage iteration as a symmetric half sweep.  The row-owner form of such an iteration gives every
-// point its halves of the pairs with one half of the points, then with the other half; the symmetric form splits the
-// PAIRS instead: `which` = 0 sweeps the pairs inside either half of the (randomly labelled) points, 1 the pairs between
-// the halves -- every point still meets half of its partners per stage (its own half, then the other one, or the
-// other way round: the order is drawn per iteration), both ends of a pair move in the same stage as in the reference
-// (src/optimization.cpp:245-281), and every pair is evaluated once per iteration instead of twice.  k_records: the
-// spring constant of the records the apply kernel leaves (this iteration's after the first stage, the next one's after
-// the second).
+// Multi-stage iterations on the symmetric sweep (relax_symm.h: sym_rr_*).  The row-owner form of an S-stage iteration gives
+// every point its halves of the pairs with one slab of the points per stage, the same slab for everybody; this form
+// splits the PAIRS: in stage st every slab a meets its partner slab (st - a) mod S -- every point still meets one slab
+// of partners per stage (the stability argument, k / S, is the same), both ends of a pair move in the same stage as in
+// the reference (src/optimization.cpp:245-281), and every pair is evaluated once per iteration instead of twice.  The
+// order of the stages is drawn per iteration.  S = 2, 4, 8; sixteen stages (the unfolding phase, k > 24) stay row-owner.
+bool sym_rr_stages_ok(int S) { return S == 2 || S == 4 || S == 8; }
+
+bool sym_rr_available(topolow_session* s, int S) {
+  auto& y = s->sym;
+  if (!sym_rr_stages_ok(S) || !y.whole) return false;
+  const int TR = y.npad / kSymRows;
+  if (TR < 2 * S) return false;
+  // a stage must give a resident wave about five tiles: below that a wave's prologue and epilogue and the apply kernel
+  // cost what the halved pair count saves, or more (config 3, tests/study/two_stage_ab.py: two stages, 6 tiles per wave:
+  // a run with k0 = 6 26.1 against 27.6 ms on the row-owner stages; four stages, 3 tiles: +25 us per iteration; eight
+  // stages, 1.5 tiles: 16.0 against 13.0 ms per run with k0 = 20)
+  if ((long long)TR * (TR + 1) / S < (long long)y.rr_min_tiles * y.grid * kSymWaves) return false;
+  int lg = S == 2 ? 1 : (S == 4 ? 2 : 3);
+  if (!y.rr[lg].empty()) return true;
+  std::vector<topolow_session::SymState::StagePlan> plans(S);
+  for (int st = 0; st < S; ++st) {
+    const SymPlan hp = relax_symm_plan_rows(y.npad, y.grid * kSymWaves, [&](int R, int& j0, int& j1) { sym_rr_row(TR, S, st, R, j0, j1); });
+    auto& h = plans[st];
+    h.n_units = (int)hp.units.size();
+    if ((size_t)h.n_units * kSymRows * s->dim > std::max(y.rowpart.n, y.rowpart64.n)) return false;   // (never: sym_build sizes for it)
+    const std::vector<SymRun> hr = hp.runs();
+    h.units.alloc(std::max<size_t>(hp.units.size(), 1));
+    h.runs.alloc(hr.size());
+    h.row_units.alloc(hp.row_units.size());
+    if (!hp.units.empty())
+      HIP_TRY(hipMemcpy(h.units.p, hp.units.data(), hp.units.size() * sizeof(SymUnit), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h.runs.p, hr.data(), hr.size() * sizeof(SymRun), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h.row_units.p, hp.row_units.data(), hp.row_units.size() * sizeof(int2), hipMemcpyHostToDevice));
+  }
+  y.rr[lg] = std::move(plans);
+  return true;
+}
+
+// Stage st of S of iteration iter.  k_records: the spring constant of the records the apply kernel leaves (this
+// iteration's until its last stage, then the next one's).
 template <int DIM>
-void sym_half_stage(topolow_session* s, const void* pin, void* pout, int iter, double k, double k_records, int which,
-                    int rec_iter_after) {
+void sym_rr_stage(topolow_session* s, const void* pin, void* pout, int iter, double k, double k_records, int S, int st,
+                  int rec_iter_after) {
   if constexpr (!kSymDim<DIM>) {
     throw HipError{TOPOLOW_ERR_UNSUPPORTED, "symmetric sweep: ndim"};
   } else {
     auto& y = s->sym;
-    auto& h = y.half[which];
+    auto& h = y.rr[S == 2 ? 1 : (S == 4 ? 2 : 3)][st];
     ProfScope prof(s, &s->prof_stage);
     const int TC = y.npad / kSymCols;
     const bool f64 = s->precision == TOPOLOW_PRECISION_F64;
@@ -990,7 +1004,7 @@ void sym_half_stage(topolow_session* s, const void* pin, void* pout, int iter, d
       if (s->any_threshold) sweep(&symm64_sweep_kernel<DIM, true, false>); else sweep(&symm64_sweep_kernel<DIM, false, false>);
       hipLaunchKernelGGL(symm64_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, s->stream, rec, y.rec64[y.rec_cur ^ 1].p,
                          (double*)pout, s->gplus.p, y.rowpart64.p, y.colpart64.p, h.row_units.p, s->n, y.npad, k_records, s->c_rep,
-                         iter + 1, s->state.p, y.split, which + 1);
+                         iter + 1, s->state.p, S, st);
     } else {
       const float* rec = y.rec[y.rec_cur].p;
       auto sweep = [&](auto kern) {
@@ -1000,7 +1014,7 @@ void sym_half_stage(topolow_session* s, const void* pin, void* pout, int iter, d
       if (s->any_threshold) sweep(&symm_sweep_kernel<DIM, true, false>); else sweep(&symm_sweep_kernel<DIM, false, false>);
       hipLaunchKernelGGL(symm_apply_kernel<DIM>, dim3(TC), dim3(32 * kSymApplyParts), 0, s->stream, rec, y.rec[y.rec_cur ^ 1].p,
                          (float*)pout, s->gplus.p, y.rowpart.p, y.colpart.p, h.row_units.p, s->n, y.npad, k_records, s->c_rep,
-                         iter + 1, s->state.p, y.split, which + 1);
+                         iter + 1, s->state.p, S, st);
     }
     HIP_TRY(hipGetLastError());
     y.rec_cur ^= 1;
@@ -1355,6 +1369,8 @@ int topolow_session_create(topolow_session** out, int32_t n, int32_t ndim, int32
     s->sym.min_n = symm_min != nullptr ? atoi(symm_min) : kSymMinPoints;
     const char* symm2 = getenv("TOPOLOW_SYMMETRIC_TWO_STAGE");
     s->sym.two_stage = !(symm2 != nullptr && symm2[0] == '0');
+    const char* rr_min = getenv("TOPOLOW_SYMMETRIC_STAGE_MIN_TILES");
+    if (rr_min != nullptr) s->sym.rr_min_tiles = std::max(0, atoi(rr_min));
     s->enc.alloc((size_t)((s->rows() + kEncRowAlign - 1) / kEncRowAlign * kEncRowAlign) * s->ld);
     const size_t pos_bytes = (size_t)s->pos_rows() * s->dim * s->real_size();
     for (auto& b : s->pos) b.alloc(pos_bytes);
@@ -1696,19 +1712,23 @@ int topolow_session_enqueue(topolow_session* s, int32_t max_iters, int32_t* enqu
         const bool fuse_now = s->pcheck.active && g.n_stages == 1 &&
                               (s->precision == TOPOLOW_PRECISION_F64 ? (sym && s->sym.delta_ready) : (sym || s->rows() % 2 == 0));
         if (s->pcheck.active && !fuse_now) flush_pending_check(s);
-        const bool sym2 = g.n_stages == 2 && s->sym.two_stage && sym_eligible(s) && sym_available(s) && s->sym.half_ready;
+        const bool symrr = s->sym.two_stage && sym_rr_stages_ok(g.n_stages) && sym_eligible(s) && sym_available(s) &&
+                           sym_rr_available(s, g.n_stages);
         if (sym) {   // one sweep over the upper triangle moves both ends of every pair
           int out = 0;
           while (out == s->cur || out == s->held) ++out;
           TL_DISPATCH_DIM(s->dim, sym_iteration, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host, fuse_now);
           s->cur = out;
-        } else if (sym2) {   // two symmetric half sweeps: the pairs inside the halves and the pairs between them, in random order
-          const int first = (int)(rnd64(s->seed, 0x2a1f5ull, (uint64_t)iter) & 1u);
-          for (int t = 0; t < 2; ++t) {
+        } else if (symrr) {   // S symmetric sweeps over the tiles of one stage each, in random order
+          const int S = g.n_stages;
+          int order[8];
+          sym_rr_order(s->seed, iter, S, order);
+          for (int t = 0; t < S; ++t) {
             int out = 0;
             while (out == s->cur || out == s->held) ++out;
-            TL_DISPATCH_DIM(s->dim, sym_half_stage, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host,
-                            t == 0 ? s->k_host : s->k_host * (1.0 - s->cooling), first ^ t, t == 0 ? iter : iter + 1);
+            const bool last = t == S - 1;
+            TL_DISPATCH_DIM(s->dim, sym_rr_stage, s, s->pos[s->cur].p, s->pos[out].p, iter, s->k_host,
+                            last ? s->k_host * (1.0 - s->cooling) : s->k_host, S, order[t], last ? iter + 1 : iter);
             s->cur = out;
           }
         } else
@@ -2018,12 +2038,20 @@ int topolow_session_controller_step(topolow_session* s, const double* d_total2, 
   });
 }
 
-int32_t topolow_symm_half_split(int32_t n) {
-  const int npad = (n + kSymRows - 1) & ~(kSymRows - 1);
-  const int split = (npad / kSymRows / 2) * kSymRows;
-  return split < n ? split : n;
+int32_t topolow_symm_stage_bounds(int32_t n, int32_t stages, int32_t* first_label) {
+  if (n < 2 || !first_label || !(stages == 2 || stages == 4 || stages == 8)) return 0;
+  const int npad = (n + kSymRows - 1) & ~(kSymRows - 1), TR = npad / kSymRows;
+  if (TR < 2 * stages) return 0;
+  for (int q = 0; q <= stages; ++q) first_label[q] = std::min(n, sym_rr_bound(TR, stages, q) * kSymRows);
+  return 1;
 }
-int32_t topolow_symm_half_first(uint64_t seed, int32_t iter) { return (int32_t)(rnd64(seed, 0x2a1f5ull, (uint64_t)iter) & 1u); }
+int32_t topolow_symm_stage_order(uint64_t seed, int32_t iter, int32_t stages, int32_t* order) {
+  if (!order || !(stages == 2 || stages == 4 || stages == 8)) return 0;
+  int perm[8];
+  sym_rr_order(seed, iter, stages, perm);
+  for (int q = 0; q < stages; ++q) order[q] = perm[q];
+  return 1;
+}
 
 int32_t topolow_symm_segment_rows(int32_t n, int32_t segment, int32_t n_segments, int32_t* row_first,
                                   int32_t* row_end) {
